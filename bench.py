@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""
+bench.py — headline benchmark of the search_relevant_metrics hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json metric "queries/sec + p50 latency, top-10 over 10M x 768 corpus at
+1/2/4/8 GPUs", quoted on configs[2]): a synthetic 10M x 768 fp32 corpus resident in HBM,
+row-sharded over the N ranks; one STEP = one batch of 256 queries answered with their exact
+top-10 (shard-local search, one RCCL all_gather of the packed partials, integer merge).
+`value` = whole-job queries/s with queries and corpus already in HBM; results stay in HBM.
+The p50 single-query (B=1) latency, host wall clock including the D2H of the 10 results, is
+reported next to it.  Prints ONE JSON line on rank 0.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (guide: ~6290 GB/s achievable)
+CHUNK_ROWS = 250_000
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--rows", type=int, default=10_000_000)
+    p.add_argument("--dim", type=int, default=768)
+    p.add_argument("--batch", type=int, default=256)
+    p.add_argument("--k", type=int, default=10)
+    p.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"])
+    p.add_argument("--latency-iters", type=int, default=30)
+    p.add_argument("--cpu-sample-rows", type=int, default=400_000)
+    p.add_argument("--cpu-sample-queries", type=int, default=32)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def planted_row(b: int, j: int, n_total: int) -> int:
+    return (b * 1_234_567 + j * 99_991 + 17) % n_total
+
+
+def build_shard(ix, torch, lo, hi, n_total, dim, queries, n_planted_q, k, device):
+    """Fill rows [lo,hi) of the GLOBAL corpus: chunk c (rows [c*CH,(c+1)*CH)) is randn with seed
+    1234+c, so the corpus is identical for every rank count; then the planted near-duplicates."""
+    ix.reserve(max(hi - lo, 1))
+    c0, c1 = lo // CHUNK_ROWS, (max(hi, 1) - 1) // CHUNK_ROWS
+    for c in range(c0, c1 + 1):
+        a, b = c * CHUNK_ROWS, min(n_total, (c + 1) * CHUNK_ROWS)
+        if b <= lo or a >= hi:
+            continue
+        g = torch.Generator(device=device).manual_seed(1234 + c)
+        x = torch.randn((b - a, dim), generator=g, device=device, dtype=torch.float32)
+        s, e = max(a, lo), min(b, hi)
+        ix.upsert_device(s - lo, x[s - a : e - a].contiguous(), normalize=True)
+        torch.cuda.synchronize()
+        del x
+    gp = torch.Generator(device=device).manual_seed(99)
+    for b in range(n_planted_q):
+        for j in range(k):
+            noise = torch.randn(dim, generator=gp, device=device)  # drawn on every rank: same stream
+            row = planted_row(b, j, n_total)
+            if lo <= row < hi:
+                vec = queries[b] + (0.02 * (j + 1)) * noise * queries[b].norm() / noise.norm()
+                ix.upsert_device(row - lo, vec[None, :].contiguous(), normalize=True)
+    torch.cuda.synchronize()
+
+
+def cpu_baseline(ix, args, queries_cpu):
+    """The oracle's all-core fp32 scan (port) on a bounded sample of the same corpus."""
+    import numpy as np
+
+    from oracle import knn_oracle as o
+
+    n = min(args.cpu_sample_rows, ix.count())
+    rows = ix.read_rows(0, n)
+    if ix.dtype != "f32":
+        rows = o.widen(rows, ix.dtype)
+    nq = min(args.cpu_sample_queries, queries_cpu.shape[0])
+    qn = o.normalize_rows(np.ascontiguousarray(queries_cpu[:nq]))
+    o.search_fast_f32(rows[:1000], qn, args.k)  # page in / warm threads
+    t0 = time.perf_counter()
+    o.search_fast_f32(rows, qn, args.k)
+    dt = time.perf_counter() - t0
+    qps_full = (nq * n / dt) / args.rows  # same work per row: scale the sample to the full corpus
+    return {
+        "value": qps_full,
+        "unit": "queries/s",
+        "cores": o.num_threads(),
+        "kind": "port",
+        "sample": f"{nq} queries x first {n} rows of the same corpus in {dt:.2f} s, scaled to {args.rows} rows "
+                  "(oracle/knn_oracle.c oracle_search_fast_f32, OpenMP; ChromaDB itself is not installable offline)",
+    }
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from codd_query_engine_amd.knn_index import DeviceKnnIndex
+    from codd_query_engine_amd.sharded import ShardedSearcher, shard_bounds
+
+    N, d, B, k = args.rows, args.dim, args.batch, args.k
+    lo, hi = shard_bounds(N, world, rank)
+    queries = torch.randn((B, d), generator=torch.Generator(device=device).manual_seed(4321), device=device)
+    n_planted_q = min(4, B)
+
+    t_build = time.perf_counter()
+    ix = DeviceKnnIndex(d, args.dtype, str(device))
+    build_shard(ix, torch, lo, hi, N, d, queries, n_planted_q, k, device)
+    t_build = time.perf_counter() - t_build
+    searcher = ShardedSearcher(ix, row_base=lo) if world > 1 else None
+
+    def step(q):
+        if searcher is not None:
+            return searcher.search(q, k)
+        return ix.search_tensors(q, k)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        dist_out, rows_out = step(queries)
+    barrier()
+
+    # correctness gate inside the bench: the planted neighbours must come back, in order
+    dist_out, rows_out = step(queries)
+    torch.cuda.synchronize()
+    expect = np.array([[planted_row(b, j, N) for j in range(k)] for b in range(n_planted_q)])
+    valid = bool(np.array_equal(rows_out[:n_planted_q].cpu().numpy(), expect))
+
+    scans_per_step = (B + 7) // 8
+    ix.set_option("profile", args.steps * scans_per_step + 8)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(queries)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    scan_ns, scan_events = ix.stat("scan_time_ns"), ix.stat("scan_events")
+    ix.set_option("profile", 0)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # p50 latency of a single query (B=1), host wall clock incl. D2H of the k results
+    lat = []
+    q1 = queries[:1].contiguous()
+    for i in range(args.latency_iters + 3):
+        barrier()
+        t1 = time.perf_counter()
+        dd, rr = step(q1)
+        rr.cpu()
+        dd.cpu()
+        if i >= 3:
+            lat.append((time.perf_counter() - t1) * 1e3)
+    p50_ms = statistics.median(lat) if lat else None
+
+    elem = 4 if args.dtype == "f32" else 2
+    n_local = hi - lo
+    ms_per_step = elapsed / args.steps * 1e3
+    qps = B * args.steps / elapsed
+    avg_launch_s = (scan_ns * 1e-9 / scan_events) if scan_events else None
+    algo_bytes_launch = n_local * d * elem  # one scan launch streams the shard once (<= 8 queries ride along)
+    achieved = (algo_bytes_launch / avg_launch_s / 1e9) if avg_launch_s else None
+
+    line = {
+        "metric": "queries/sec, top-10 over 10M x 768 corpus",
+        "value": qps,
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {
+            "workload": f"{N} x {d} {args.dtype} corpus, batch={B} queries, top-{k}, exact cosine (BASELINE configs[2])",
+            "rows": N, "dim": d, "batch": B, "k": k,
+            "parallelism": f"row-sharded x{world}, one all_gather of B*k u64 per rank" if world > 1 else "single GPU",
+            "rows_per_gpu": n_local,
+        },
+        "p50_latency_ms_batch1": p50_ms,
+        "results_valid": valid,
+        "index_build_s": t_build,
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "scan_topk_kernel",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": algo_bytes_launch,
+            "avg_launch_ms": avg_launch_s * 1e3 if avg_launch_s else None,
+            "launches_timed": scan_events,
+            "launches_per_step": scans_per_step,
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = cpu_baseline(ix, args, queries.cpu().numpy())
+        except Exception as e:  # the baseline must never take the GPU number down with it
+            line["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": None, "kind": "port", "sample": f"failed: {e}"}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    ix.close()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    if not valid:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

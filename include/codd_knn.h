@@ -1,0 +1,129 @@
+/*
+ * codd_knn.h — C ABI of the MI355X-native cosine top-k engine that stands where
+ * ChromaDB stands on Codd's `search_relevant_metrics` path.
+ *
+ * The reference has no FFI of its own: its seam is Python duck typing on the
+ * chromadb client object injected into MetricsSemanticMetadataStore
+ * (/root/reference/codd_dal/metrics/metrics_semantic_metadata_store.py:43-57).
+ * Each entry point below names the chromadb call it takes over; string ids,
+ * documents and metadata never cross this boundary (the Python façade
+ * codd_query_engine_amd/knn_client.py keeps id <-> row slot and metadata on the
+ * host, exactly the part of chromadb that is not arithmetic).
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative CODD_KNN_E* code on
+ *     failure; it never throws, aborts or exits.  codd_knn_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.
+ *   - "dev_" pointers are device (HBM) addresses on the index's GPU, "host_"
+ *     pointers are ordinary host memory.  The caller owns every buffer it passes;
+ *     the index owns its row storage and its workspaces.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls
+ *     are asynchronous with respect to the host unless stated otherwise.
+ *   - thread-safety: searches on distinct streams may run concurrently only on
+ *     distinct indexes (an index owns one workspace); upsert/reserve are exclusive.
+ *   - rows are stored L2-normalised, zero padded to a multiple of 64 elements.
+ *     score = <q/|q|, c/|c|> evaluated in fp32 in the canonical order of
+ *     DESIGN.md §3; distance = 1 - score (fp32); ties -> lower row.
+ */
+#ifndef CODD_KNN_H
+#define CODD_KNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CODD_KNN_DTYPE_F32 0
+#define CODD_KNN_DTYPE_BF16 1
+#define CODD_KNN_DTYPE_F16 2
+
+/* `hnsw:space` of get_or_create_collection (store.py:63-68); only cosine exists on the path */
+#define CODD_KNN_METRIC_COSINE 0
+
+#define CODD_KNN_MAX_K 128        /* reference caps n_results at 100 (store.py:24) */
+#define CODD_KNN_MAX_BATCH 1024   /* queries per codd_knn_search call */
+
+#define CODD_KNN_OK 0
+#define CODD_KNN_EINVAL (-22)     /* bad argument */
+#define CODD_KNN_ENOMEM (-12)     /* device allocation failed */
+#define CODD_KNN_EDEVICE (-5)     /* HIP runtime error */
+#define CODD_KNN_ENOTSUP (-95)    /* shape/dtype outside what the kernels cover */
+
+typedef struct codd_knn_index codd_knn_index;
+
+/* library / build identification: "codd_knn <semver> gfx950" */
+const char* codd_knn_version(void);
+const char* codd_knn_last_error(void);
+
+/*
+ * Replaces: client.get_or_create_collection(name=..., metadata={"hnsw:space":"cosine",...})
+ *           (store.py:60-69) — the arithmetic half: an empty device-resident row store.
+ * dim: embedding width (<= 4096; f32 rows <= 1024 in this release).
+ */
+int codd_knn_create(codd_knn_index** out, int device, int dim, int dtype, int metric);
+int codd_knn_destroy(codd_knn_index* index);
+
+/* Grow row storage to hold at least `rows` row slots (contents preserved). Synchronous. */
+int codd_knn_reserve(codd_knn_index* index, int64_t rows);
+
+/*
+ * Replaces: collection.upsert(documents=[...], metadatas=[...], ids=[...]) (store.py:236-238)
+ *           — the vector half.  Writes `n` fp32 vectors (row stride `dim`) into the row
+ *           slots chosen by the host id-map; a slot may be new (append) or existing
+ *           (overwrite).  normalize != 0 scales each vector to unit L2 norm first
+ *           (always what the façade asks for; 0 is for callers that already did).
+ *           Storage grows as needed.  The host variant stages through pinned memory and
+ *           is synchronous; the device variant writes slots [first_slot, first_slot+n).
+ */
+int codd_knn_upsert_host(codd_knn_index* index, const int64_t* host_slots, const float* host_vecs,
+                         int64_t n, int normalize);
+int codd_knn_upsert_device(codd_knn_index* index, int64_t first_slot, const float* dev_vecs,
+                           int64_t n, int normalize, void* stream);
+
+/* Number of row slots in use (highest written slot + 1) — collection.count(). */
+int codd_knn_count(const codd_knn_index* index, int64_t* out);
+int codd_knn_dim(const codd_knn_index* index, int* dim, int* padded_dim, int* dtype);
+
+/* Copy stored rows [first, first+n) back to the host, in storage dtype, padded width.
+ * (persistence + tests).  Synchronous. */
+int codd_knn_read_rows(const codd_knn_index* index, int64_t first, int64_t n, void* host_out);
+
+/*
+ * Replaces: collection.query(query_texts=[q], n_results=n) (store.py:314-316) — the k-NN
+ *           half, batched.  dev_queries: B x dim fp32, raw (normalised here).
+ *           dev_dist : B x k fp32, ascending distance (1 - score), +inf padded.
+ *           dev_rows : B x k int64 row slots, -1 padded (fewer than k rows stored).
+ */
+int codd_knn_search(codd_knn_index* index, const float* dev_queries, int B, int k,
+                    float* dev_dist, int64_t* dev_rows, void* stream);
+
+/*
+ * Shard-local half of a row-sharded search: same as codd_knn_search but returns packed
+ * keys, key = (orderable_u32(score) << 32) | (0xFFFFFFFF - (row_base + row)), descending,
+ * 0 = empty slot — so that the cross-rank merge is an integer top-k (codd_knn_merge_keys).
+ */
+int codd_knn_search_keys(codd_knn_index* index, const float* dev_queries, int B, int k,
+                         uint32_t row_base, uint64_t* dev_keys, void* stream);
+
+/*
+ * Top-k of B lists of m packed keys each (the all-gathered [B][G*k] shard partials).
+ * Any of dev_keys_out / dev_dist / dev_rows may be NULL.  `device` as in codd_knn_create.
+ */
+int codd_knn_merge_keys(int device, const uint64_t* dev_keys_in, int B, int m, int k,
+                        uint64_t* dev_keys_out, float* dev_dist, int64_t* dev_rows, void* stream);
+
+/*
+ * Tuning / introspection (never needed for correctness).
+ *   options: "scan_blocks_per_cu" (1..8); "profile" = N keeps N (start, stop) HIP-event
+ *            pairs, one per scan-kernel launch, recorded on the launch stream (0 = off)
+ *   stats  : "searches", "scan_launches", "last_scan_blocks", "capacity_rows",
+ *            "device_bytes", "num_cus", "scan_events", "scan_time_ns" (syncs on the last event)
+ */
+int codd_knn_set_option(codd_knn_index* index, const char* key, int64_t value);
+int codd_knn_get_stat(const codd_knn_index* index, const char* key, int64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CODD_KNN_H */

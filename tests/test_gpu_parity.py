@@ -1,0 +1,202 @@
+"""GPU parity: the HIP path, called through the C ABI (ctypes), against the CPU oracle.
+
+Bar: ids bit-exact; distances bit-exact against the canonical C restatement and within
+2e-6 of the fp64 brute force; stored rows (ingest) bit-exact.  All tests run in ONE process.
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+from oracle import knn_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+TOL_F64 = 2e-6  # |score_fp32 - score_fp64| for unit-norm rows, fp32 accumulation
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def Index(torch):
+    from codd_query_engine_amd.knn_index import DeviceKnnIndex
+
+    return DeviceKnnIndex
+
+
+@pytest.fixture(scope="module")
+def golden(golden_dir):
+    return np.load(os.path.join(golden_dir, "knn_golden.npz"))
+
+
+def build(Index, raw, dtype, normalize=True):
+    ix = Index(raw.shape[1], dtype=dtype)
+    ix.upsert(np.arange(raw.shape[0], dtype=np.int64), raw, normalize=normalize)
+    return ix
+
+
+def check_against_oracle(ix, raw, q_raw, k, dtype):
+    rows_ref = o.to_storage(o.normalize_rows(raw), dtype)
+    assert np.array_equal(ix.read_rows(), rows_ref), "ingest kernel differs from the oracle"
+    qn = o.normalize_rows(q_raw)
+    d_ref, i_ref = o.search(rows_ref, dtype, qn, k)
+    d_gpu, i_gpu = ix.search(q_raw, k)
+    assert np.array_equal(i_gpu, i_ref), "ids differ from the canonical oracle"
+    assert np.array_equal(d_gpu, d_ref), "distances are not bit-identical to the canonical oracle"
+    sc64, _ = o.search_f64(o.widen(rows_ref, dtype), qn, k)
+    valid = i_ref >= 0
+    assert np.abs((1.0 - d_gpu.astype(np.float64))[valid] - sc64[valid]).max() <= TOL_F64
+
+
+GOLDEN_CASES = ["rand_f32", "rand_bf16", "rand_f16", "odd_dim_f32", "ties_zero_f32", "near_ties_f32", "few_rows_f32", "k100_f32"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_golden_fixtures(Index, golden, name):
+    dtype, k = str(golden[f"{name}/dtype"]), int(golden[f"{name}/k"])
+    raw, q_raw = golden[f"{name}/raw"], golden[f"{name}/q_raw"]
+    ix = build(Index, raw, dtype)
+    assert np.array_equal(ix.read_rows(), golden[f"{name}/rows"])
+    d, i = ix.search(q_raw, k)
+    assert np.array_equal(i, golden[f"{name}/ids"])
+    assert np.array_equal(d, golden[f"{name}/dist"])
+    ix.close()
+
+
+@pytest.mark.parametrize(
+    "n,d,B,k,dtype",
+    [
+        (5000, 768, 1, 10, "f32"),     # the B=1 latency shape
+        (5000, 768, 8, 10, "f32"),
+        (3001, 768, 13, 10, "f32"),    # ragged batch: 8 + 4(+1 pad) + 1
+        (4097, 384, 3, 5, "f32"),      # MiniLM width, lanes 32..63 own one chunk fewer
+        (2000, 1024, 4, 100, "f32"),   # widest f32 row, API cap k=100 (two list slots)
+        (1000, 64, 2, 64, "f32"),
+        (1500, 100, 2, 65, "f32"),     # dim padded 100 -> 128; k just over one slot
+        (4000, 768, 5, 10, "bf16"),
+        (4000, 1024, 2, 10, "f16"),
+        (777, 2048, 1, 10, "bf16"),
+        (3, 768, 2, 10, "f32"),        # fewer rows than k, fewer than one row group
+        (1, 64, 1, 1, "f32"),
+    ],
+)
+def test_seeded_shapes_match_oracle(Index, n, d, B, k, dtype):
+    rng = np.random.default_rng(n * 7 + d + B)
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    q_raw = rng.standard_normal((B, d)).astype(np.float32)
+    ix = build(Index, raw, dtype)
+    check_against_oracle(ix, raw, q_raw, k, dtype)
+    ix.close()
+
+
+def test_empty_index_returns_padding(Index):
+    ix = Index(128)
+    d, i = ix.search(np.ones((3, 128), dtype=np.float32), 5)
+    assert (i == -1).all() and np.isinf(d).all()
+    ix.close()
+
+
+def test_upsert_overwrites_in_place_and_grows(Index):
+    rng = np.random.default_rng(3)
+    raw = rng.standard_normal((600, 256)).astype(np.float32)
+    ix = Index(256)
+    ix.upsert(np.arange(100, dtype=np.int64), raw[:100])
+    ix.upsert(np.arange(100, 600, dtype=np.int64), raw[100:])          # growth keeps old rows
+    new = rng.standard_normal((3, 256)).astype(np.float32)
+    ix.upsert(np.array([5, 250, 599], dtype=np.int64), new)            # overwrite, scattered slots
+    raw[[5, 250, 599]] = new
+    assert ix.count() == 600
+    check_against_oracle(ix, raw, rng.standard_normal((4, 256)).astype(np.float32), 10, "f32")
+    ix.close()
+
+
+def test_device_upsert_equals_host_upsert(Index, torch):
+    rng = np.random.default_rng(4)
+    raw = rng.standard_normal((1000, 768)).astype(np.float32)
+    a = build(Index, raw, "f32")
+    b = Index(768)
+    b.reserve(1000)
+    t = torch.from_numpy(raw).cuda()
+    b.upsert_device(0, t[:400])
+    b.upsert_device(400, t[400:].contiguous())
+    torch.cuda.synchronize()
+    assert np.array_equal(a.read_rows(), b.read_rows())
+    a.close(); b.close()
+
+
+def test_search_keys_and_merge_equal_whole_index(Index, torch):
+    """Two shards + codd_knn_merge_keys == one index over all rows (the multi-GPU identity)."""
+    rng = np.random.default_rng(5)
+    raw = rng.standard_normal((3000, 768)).astype(np.float32)
+    q = rng.standard_normal((9, 768)).astype(np.float32)
+    whole = build(Index, raw, "f32")
+    d_ref, i_ref = whole.search(q, 10)
+    cut = 1111
+    s0, s1 = build(Index, raw[:cut], "f32"), build(Index, raw[cut:], "f32")
+    keys = torch.cat([s0.search_keys(q, 10, 0), s1.search_keys(q, 10, cut)], dim=1)
+    _, d, i = s0.merge_keys(keys, 10)
+    assert np.array_equal(i.cpu().numpy(), i_ref) and np.array_equal(d.cpu().numpy(), d_ref)
+    # and against the oracle's key arithmetic
+    rows_ref = o.normalize_rows(raw)
+    k_ref = o.search_keys(rows_ref, "f32", o.normalize_rows(q), 10)
+    merged_keys = s0.merge_keys(keys, 10)[0].cpu().numpy().view(np.uint64)
+    assert np.array_equal(merged_keys, k_ref)
+    for ix in (whole, s0, s1):
+        ix.close()
+
+
+def test_planted_neighbours_at_scale(Index, torch):
+    """Size-independent property at a size the oracle cannot brute-force quickly: 10 planted
+    near-duplicates of each query must come back, in order of their planted closeness, from a
+    1M-row corpus generated on the device."""
+    n, d, B, k = 1_000_000, 768, 4, 10
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    ix = Index(d)
+    ix.reserve(n)
+    chunk = 250_000
+    for c in range(n // chunk):
+        ix.upsert_device(c * chunk, torch.randn((chunk, d), generator=g, device="cuda", dtype=torch.float32))
+    q = torch.randn((B, d), generator=torch.Generator(device="cuda").manual_seed(4321), device="cuda")
+    planted_rows = []
+    for b in range(B):
+        for j in range(k):
+            row = 1000 + b * 50_000 + j * 7
+            noise = torch.randn(d, generator=g, device="cuda")
+            vec = q[b] + (0.02 * (j + 1)) * noise * q[b].norm() / noise.norm()
+            ix.upsert_device(row, vec[None, :].contiguous())
+            planted_rows.append(row)
+    torch.cuda.synchronize()
+    dist, rows = ix.search(q.cpu().numpy(), k)
+    expect = np.array(planted_rows).reshape(B, k)
+    assert np.array_equal(rows, expect)
+    assert (np.diff(dist, axis=1) >= 0).all() and dist.max() < 0.05
+    # spot-check scores of the winners against the oracle on exactly those rows
+    stored = np.concatenate([ix.read_rows(int(r), 1) for r in expect[0]])
+    qn = o.normalize_rows(q[:1].cpu().numpy())
+    for j in range(k):
+        assert np.float32(1.0) - np.float32(o.canon_dot(qn[0], stored[j])) == dist[0, j]
+    ix.close()
+
+
+def test_facade_and_store_run_on_the_hip_engine():
+    from codd_query_engine_amd import KnnClient, MetricsSemanticMetadataStore
+    from tests._oracle_engine import OracleEngine
+
+    gpu = MetricsSemanticMetadataStore(KnnClient(device="cuda:0"))
+    cpu = MetricsSemanticMetadataStore(KnnClient(engine_factory=lambda dim: OracleEngine(dim)))
+    words = ["cpu", "memory", "disk", "network", "latency", "errors", "requests", "queue", "cache", "gc", "threads", "io"]
+    rng = np.random.default_rng(0)
+    for i in range(300):
+        w = rng.choice(words, size=4, replace=False)
+        md = {"metric_name": f"svc.m{i}", "description": " ".join(w) + f" metric {i}", "category": w[0], "golden_signal_type": w[1]}
+        gpu.index_metadata("ns", md)
+        cpu.index_metadata("ns", md)
+    for query in ["cpu latency", "disk io errors", "cache memory threads", "requests queue"]:
+        assert gpu.search_metadata(query, n_results=20) == cpu.search_metadata(query, n_results=20)
