@@ -4,14 +4,16 @@
 // (reference call sites: codd_dal/metrics/metrics_semantic_metadata_store.py:60-69 create,
 // :236-238 upsert, :314-316 query; scoring :336).  Kernels:
 //
-//   normalize_rows_kernel   ingest + query prep: c <- c/|c| (canonical sum of squares, IEEE sqrt/div)
-//   scan_topk_kernel        exact streaming scan: one wave owns 4 rows per step, 16-B/lane coalesced
-//                           loads, fmaf chains in canonical order, wave-distributed top-k lists
+//   normalize_rows_kernel   ingest + query prep: c <- c/|c| (canonical sum of squares, IEEE sqrt/div),
+//                           writes the stored row AND its bf16 shadow in MFMA-fragment order
+//   scan_topk_kernel        exact streaming scan (small batches, fallback): one wave owns 4 rows per
+//                           step, 16-B/lane coalesced loads, fmaf chains in canonical order,
+//                           wave-distributed top-k lists
 //   merge_keys_kernel       integer top-k of packed keys (per-block partials, shard partials)
+//   filter_gemm.h           large batches: bf16 MFMA filter + exact fp32 re-score (finalize)
 //
-// HBM-bound byte streaming: no LDS staging of the corpus (each row is consumed by exactly one
-// wave, so an LDS round trip would be pure overhead — guide §5 "GEMV / M <= 16" row), many
-// 16-B loads in flight per lane, results leave as 8-byte keys.
+// HBM-bound byte streaming throughout: the corpus is read once per pass, each row by exactly one
+// wave, straight into registers; results leave as 8-byte keys.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -20,6 +22,8 @@
 #include <vector>
 
 #include "codd_knn.h"
+#include "filter_gemm.h"
+#include "row_traits.h"
 #include "wave_topk.h"
 
 using namespace codd;
@@ -30,72 +34,24 @@ using namespace codd;
 
 namespace {
 
-constexpr int DT_F32 = CODD_KNN_DTYPE_F32;
-constexpr int DT_BF16 = CODD_KNN_DTYPE_BF16;
-constexpr int DT_F16 = CODD_KNN_DTYPE_F16;
-
-template <int DT>
-struct RowTraits;
-template <>
-struct RowTraits<DT_F32> {
-    static constexpr int E = 4;      // elements per 16-byte chunk
-    static constexpr int ESIZE = 4;  // bytes per element
-    static __device__ __forceinline__ void widen(const uint4& c, float* w) {
-        w[0] = __uint_as_float(c.x); w[1] = __uint_as_float(c.y);
-        w[2] = __uint_as_float(c.z); w[3] = __uint_as_float(c.w);
-    }
-};
-template <>
-struct RowTraits<DT_BF16> {
-    static constexpr int E = 8;
-    static constexpr int ESIZE = 2;
-    static __device__ __forceinline__ void widen(const uint4& c, float* w) {
-        w[0] = __uint_as_float(c.x << 16); w[1] = __uint_as_float(c.x & 0xffff0000u);
-        w[2] = __uint_as_float(c.y << 16); w[3] = __uint_as_float(c.y & 0xffff0000u);
-        w[4] = __uint_as_float(c.z << 16); w[5] = __uint_as_float(c.z & 0xffff0000u);
-        w[6] = __uint_as_float(c.w << 16); w[7] = __uint_as_float(c.w & 0xffff0000u);
-    }
-};
-template <>
-struct RowTraits<DT_F16> {
-    static constexpr int E = 8;
-    static constexpr int ESIZE = 2;
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    static __device__ __forceinline__ void widen(const uint4& c, float* w) {
-        const h2 a = __builtin_bit_cast(h2, c.x), b = __builtin_bit_cast(h2, c.y);
-        const h2 d = __builtin_bit_cast(h2, c.z), e = __builtin_bit_cast(h2, c.w);
-        w[0] = (float)a[0]; w[1] = (float)a[1]; w[2] = (float)b[0]; w[3] = (float)b[1];
-        w[4] = (float)d[0]; w[5] = (float)d[1]; w[6] = (float)e[0]; w[7] = (float)e[1];
-    }
-};
-
-// fp32 -> storage element, round to nearest even (bit-identical to oracle/knn_oracle.c)
-__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-__device__ __forceinline__ uint16_t f32_to_f16_rne(float f) {
-    const _Float16 h = (_Float16)f;  // v_cvt_f16_f32, RNE in the default mode
-    return __builtin_bit_cast(uint16_t, h);
-}
-
 // ---------------------------------------------------------------------------------------------
 // normalize_rows_kernel: one wave per input vector.  in: n x d fp32 (row stride d).
 // out row = slots ? slots[r] : first_slot + r, width dpad, storage dtype DT.
 // Sum of squares in the canonical order with E = 4 (the input is fp32), then IEEE sqrt and
 // IEEE division per element; a zero / non-finite norm stores an all-zero row.
+// shadow (optional): the bf16 rounding of the STORED value, in fragment order (filter_gemm.h).
 // ---------------------------------------------------------------------------------------------
 template <int DT>
 __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ in, int64_t n, int d, int dpad,
                                                              int normalize, const int64_t* __restrict__ slots,
-                                                             int64_t first_slot, void* __restrict__ out_) {
+                                                             int64_t first_slot, void* __restrict__ out_,
+                                                             uint2* __restrict__ shadow) {
     const int lane = lane_id();
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n) return;
     const float* x = in + r * (int64_t)d;
     const int nch = dpad >> 2;
+    const int nsteps = dpad >> 6;
     float scale_div = 1.0f;
     bool zero_row = false;
     if (normalize) {
@@ -127,11 +83,19 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
             float4* o = reinterpret_cast<float4*>(out_) + orow * (int64_t)nch + j;
             *o = make_float4(v[0], v[1], v[2], v[3]);
         } else {
-            uint16_t h[4];
+            uint16_t hb[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) h[e] = DT == DT_BF16 ? f32_to_bf16_rne(v[e]) : f32_to_f16_rne(v[e]);
+            for (int e = 0; e < 4; ++e) {
+                hb[e] = DT == DT_BF16 ? f32_to_bf16_rne(v[e]) : f32_to_f16_rne(v[e]);
+                if (DT == DT_F16) v[e] = f16_bits_to_f32(hb[e]);  // the shadow approximates the STORED value
+            }
             uint2* o = reinterpret_cast<uint2*>(out_) + orow * (int64_t)nch + j;
-            *o = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+            *o = make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
+        }
+        if (shadow) {
+            // elements [4j, 4j+4) = half (j&1) of 16-byte piece c8 = j>>1
+            const int64_t piece = shadow_piece_index(orow, j >> 1, nsteps);
+            shadow[piece * 2 + (j & 1)] = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
         }
     }
 }
@@ -241,16 +205,16 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const void* __restrict__
 
 // ---------------------------------------------------------------------------------------------
 // merge_keys_kernel: block b reduces in[b][0..m) to its k largest keys (descending) and writes
-// keys and/or (distance, row).  Used for the per-block partials of a scan and for the
-// all-gathered shard partials.
+// keys and/or (distance, row).  Used for the per-block partials of a scan, for the all-gathered
+// shard partials, and (m == k) to unpack final keys.
 // ---------------------------------------------------------------------------------------------
 template <int SLOTS>
-__global__ __launch_bounds__(256) void merge_keys_kernel(const u64* __restrict__ in, int64_t m, int k,
+__global__ __launch_bounds__(256) void merge_keys_kernel(const u64* __restrict__ in, int64_t m, int64_t in_stride, int k,
                                                          u64* __restrict__ out_keys, float* __restrict__ out_dist,
                                                          int64_t* __restrict__ out_rows) {
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
-    const u64* src = in + (int64_t)blockIdx.x * m;
+    const u64* src = in + (int64_t)blockIdx.x * in_stride;
     WaveTopK<SLOTS> L;
     L.init();
     for (int64_t i0 = (int64_t)wave * kWave; i0 < m; i0 += 256) {
@@ -283,11 +247,39 @@ __global__ __launch_bounds__(256) void merge_keys_kernel(const u64* __restrict__
     }
 }
 
+// gathers the fallback queries' normalised vectors into a dense block: dst[i] = qn[list[i]]
+__global__ __launch_bounds__(256) void gather_queries_kernel(const float* __restrict__ qn, const unsigned* __restrict__ list,
+                                                             int count, int dpad, float* __restrict__ dst) {
+    const int i = blockIdx.x;
+    if (i >= count) return;
+    const float* src = qn + (int64_t)list[i] * dpad;
+    for (int j = threadIdx.x; j < dpad; j += 256) dst[(int64_t)i * dpad + j] = src[j];
+}
+// scatter the fallback results back: out[list[i]] = src[i]
+__global__ __launch_bounds__(128) void scatter_keys_kernel(const u64* __restrict__ src, const unsigned* __restrict__ list,
+                                                           int count, int k, u64* __restrict__ out) {
+    const int i = blockIdx.x;
+    if (i >= count) return;
+    for (int j = threadIdx.x; j < k; j += 128) out[(int64_t)list[i] * k + j] = src[(int64_t)i * k + j];
+}
+
 }  // namespace
 
 // =============================================================================================
 // host side: the index object and the C ABI
 // =============================================================================================
+
+enum { EV_SCAN = 0, EV_FILTER = 1, EV_SAMPLE = 2, EV_FINALIZE = 3, EV_KINDS = 4 };
+static const char* const kEvNames[EV_KINDS] = {"scan", "filter", "sample", "finalize"};
+
+// device control block of one filter pass (zeroed by ONE memset per pass)
+struct FilterCtl {
+    unsigned hit_cnt[kTileQ];
+    unsigned flags[FLAG_WORDS];
+    unsigned fb_count;
+    unsigned stats[3];  // hits, survivors, (spare)
+    unsigned fb_list[kTileQ];
+};
 
 struct codd_knn_index {
     int device = 0;
@@ -300,24 +292,39 @@ struct codd_knn_index {
     int64_t capacity = 0;  // row slots allocated
     int64_t count = 0;     // highest written slot + 1
     void* rows = nullptr;  // [capacity][dpad] storage dtype
+    uint4* shadow = nullptr;       // bf16 fragment-order copy, whole 256-row tiles
+    int64_t shadow_rows = 0;       // rows the shadow allocation covers (multiple of 256)
+    bool all_normalized = true;    // false once a caller stored rows with normalize = 0
+
+    // filter path knobs
+    int filter_enabled = 1;
+    int64_t filter_min_rows = 32768;
+    int filter_min_batch = 16;
+    int sample_tiles = 1024;
+    int hit_cap_q = 8192;
 
     // workspaces (grown on demand, never inside a captured region after warm-up)
-    float* qn = nullptr;       // [B][dpad] normalised queries
-    int64_t qn_cap = 0;        // in queries
-    u64* partial = nullptr;    // [B][blocks][k]
-    int64_t partial_cap = 0;   // in keys
-    u64* keys_tmp = nullptr;   // [B][k] for codd_knn_search
-    int64_t keys_tmp_cap = 0;
+    float* qn = nullptr;       int64_t qn_cap = 0;        // [B][dpad] normalised queries
+    u64* partial = nullptr;    int64_t partial_cap = 0;   // [B][blocks][k]
+    u64* keys_tmp = nullptr;   int64_t keys_tmp_cap = 0;  // [B][k]
+    uint4* qfrag = nullptr;    int64_t qfrag_cap = 0;     // pieces
+    float* thr = nullptr;                                  // [256]
+    float* bucket_max = nullptr; int64_t bucket_cap = 0;   // [sample tiles][256]
+    u64* hits = nullptr;       int64_t hits_cap = 0;      // [256][hit_cap_q]
+    FilterCtl* ctl = nullptr;                              // device
+    FilterCtl* ctl_host = nullptr;                         // pinned host mirror
+    float* qn_fb = nullptr;    int64_t qn_fb_cap = 0;     // gathered fallback queries
+    u64* keys_fb = nullptr;    int64_t keys_fb_cap = 0;
 
-    int64_t stat_searches = 0;
-    int64_t stat_scan_launches = 0;
-    int64_t stat_last_scan_blocks = 0;
+    int64_t stat_searches = 0, stat_scan_launches = 0, stat_last_scan_blocks = 0;
+    int64_t stat_filter_passes = 0, stat_fallback_queries = 0, stat_hits = 0, stat_survivors = 0;
 
-    // optional HIP-event timing of the dominant kernel (bench.py's roofline figure):
-    // one (start, stop) pair per scan launch, recorded on the launch stream, read after a sync
+    // optional HIP-event timing of the heavy kernels (bench.py's roofline figure): one (start, stop)
+    // pair per launch, recorded on the launch stream, read after a sync
     bool profile = false;
     std::vector<hipEvent_t> ev;  // 2 * pairs
-    int ev_used = 0;             // pairs recorded since the last reset
+    std::vector<int> ev_kind;
+    int ev_used = 0;
 };
 
 namespace {
@@ -342,36 +349,69 @@ struct DeviceGuard {
     int prev = -1;
     bool changed = false;
     explicit DeviceGuard(int dev) {
-        if (hipGetDevice(&prev) == hipSuccess && prev != dev) {
-            changed = hipSetDevice(dev) == hipSuccess;
-        }
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) changed = hipSetDevice(dev) == hipSuccess;
     }
     ~DeviceGuard() {
         if (changed) (void)hipSetDevice(prev);
     }
 };
 
+struct EvScope {  // records a (start, stop) pair around one launch when profiling is on
+    codd_knn_index* ix;
+    hipStream_t st;
+    int slot = -1;
+    EvScope(codd_knn_index* ix_, int kind, hipStream_t st_) : ix(ix_), st(st_) {
+        if (ix->profile && 2 * (ix->ev_used + 1) <= (int)ix->ev.size()) {
+            slot = ix->ev_used++;
+            ix->ev_kind[slot] = kind;
+            (void)hipEventRecord(ix->ev[2 * slot], st);
+        }
+    }
+    ~EvScope() {
+        if (slot >= 0) (void)hipEventRecord(ix->ev[2 * slot + 1], st);
+    }
+};
+
 size_t elem_size(int dtype) { return dtype == DT_F32 ? 4 : 2; }
 int elems_per_chunk(int dtype) { return dtype == DT_F32 ? 4 : 8; }
 
-int ensure_rows(codd_knn_index* ix, int64_t need) {
+// (re)allocate row storage + shadow for at least `need` slots, preserving contents
+int grow_rows(codd_knn_index* ix, int64_t need, bool exact) {
     if (need <= ix->capacity) return CODD_KNN_OK;
-    int64_t cap = ix->capacity > 0 ? ix->capacity : 1024;
-    while (cap < need) cap += cap / 2 + 1024;
-    if (need > cap) cap = need;
-    void* fresh = nullptr;
+    int64_t cap = need;
+    if (!exact) {
+        cap = ix->capacity > 0 ? ix->capacity : 1024;
+        while (cap < need) cap += cap / 2 + 1024;
+    }
     const size_t row_bytes = (size_t)ix->dpad * elem_size(ix->dtype);
+    const int64_t srows = (cap + kTileRows - 1) / kTileRows * kTileRows;
+    const size_t shadow_bytes = (size_t)srows * ix->dpad * 2;
+    void* fresh = nullptr;
+    uint4* fresh_shadow = nullptr;
     HIP_TRY(hipMalloc(&fresh, (size_t)cap * row_bytes));
-    if (ix->rows && ix->count > 0) {
-        hipError_t e = hipMemcpy(fresh, ix->rows, (size_t)ix->count * row_bytes, hipMemcpyDeviceToDevice);
-        if (e != hipSuccess) {
-            (void)hipFree(fresh);
-            return fail(CODD_KNN_EDEVICE, "row copy on growth failed: %s", hipGetErrorString(e));
-        }
+    if (hipMalloc((void**)&fresh_shadow, shadow_bytes) != hipSuccess) {
+        (void)hipFree(fresh);
+        return fail(CODD_KNN_ENOMEM, "shadow allocation failed%s");
+    }
+    hipError_t e = hipMemset(fresh, 0, (size_t)cap * row_bytes);
+    if (e == hipSuccess) e = hipMemset(fresh_shadow, 0, shadow_bytes);
+    if (e == hipSuccess && ix->rows && ix->count > 0) {
+        e = hipMemcpy(fresh, ix->rows, (size_t)ix->count * row_bytes, hipMemcpyDeviceToDevice);
+        // the shadow is block-major (32-row blocks are contiguous): copy the blocks in use
+        const int64_t blocks = (ix->count + 31) / 32;
+        if (e == hipSuccess) e = hipMemcpy(fresh_shadow, ix->shadow, (size_t)blocks * 32 * ix->dpad * 2, hipMemcpyDeviceToDevice);
+    }
+    if (e != hipSuccess) {
+        (void)hipFree(fresh);
+        (void)hipFree(fresh_shadow);
+        return fail(CODD_KNN_EDEVICE, "row copy on growth failed: %s", hipGetErrorString(e));
     }
     if (ix->rows) (void)hipFree(ix->rows);
+    if (ix->shadow) (void)hipFree(ix->shadow);
     ix->rows = fresh;
+    ix->shadow = fresh_shadow;
     ix->capacity = cap;
+    ix->shadow_rows = srows;
     return CODD_KNN_OK;
 }
 
@@ -390,18 +430,18 @@ int ensure_buf(T** buf, int64_t* cap, int64_t need) {
 }
 
 int launch_normalize(int dtype, const float* in, int64_t n, int d, int dpad, int normalize, const int64_t* slots,
-                     int64_t first_slot, void* out, hipStream_t st) {
+                     int64_t first_slot, void* out, uint2* shadow, hipStream_t st) {
     if (n <= 0) return CODD_KNN_OK;
     const dim3 grid((unsigned)((n + 3) / 4)), block(256);
     switch (dtype) {
         case DT_F32:
-            hipLaunchKernelGGL(normalize_rows_kernel<DT_F32>, grid, block, 0, st, in, n, d, dpad, normalize, slots, first_slot, out);
+            hipLaunchKernelGGL(normalize_rows_kernel<DT_F32>, grid, block, 0, st, in, n, d, dpad, normalize, slots, first_slot, out, shadow);
             break;
         case DT_BF16:
-            hipLaunchKernelGGL(normalize_rows_kernel<DT_BF16>, grid, block, 0, st, in, n, d, dpad, normalize, slots, first_slot, out);
+            hipLaunchKernelGGL(normalize_rows_kernel<DT_BF16>, grid, block, 0, st, in, n, d, dpad, normalize, slots, first_slot, out, shadow);
             break;
         case DT_F16:
-            hipLaunchKernelGGL(normalize_rows_kernel<DT_F16>, grid, block, 0, st, in, n, d, dpad, normalize, slots, first_slot, out);
+            hipLaunchKernelGGL(normalize_rows_kernel<DT_F16>, grid, block, 0, st, in, n, d, dpad, normalize, slots, first_slot, out, shadow);
             break;
         default:
             return fail(CODD_KNN_EINVAL, "unknown dtype%s");
@@ -410,50 +450,240 @@ int launch_normalize(int dtype, const float* in, int64_t n, int d, int dpad, int
     return CODD_KNN_OK;
 }
 
+// ---- exact scan dispatch ---------------------------------------------------------------------
+
+struct ScanArgs {
+    const void* rows;
+    int64_t n;
+    int dpad;
+    const float* qn;
+    int nq, k;
+    uint32_t row_base;
+    u64* partial;
+    int64_t stride_q;
+};
+
 template <int DT, int NB, int NITER>
-void launch_scan_slots(int slots, dim3 grid, size_t lds, hipStream_t st, const void* rows, int64_t n, int dpad,
-                       const float* qn, int nq, int k, uint32_t row_base, u64* partial, int64_t stride_q) {
+void launch_scan_slots(int slots, dim3 grid, size_t lds, hipStream_t st, const ScanArgs& a) {
     if (slots == 1)
-        hipLaunchKernelGGL((scan_topk_kernel<DT, NB, NITER, 1>), grid, dim3(256), lds, st, rows, n, dpad, qn, nq, k, row_base, partial, stride_q);
+        hipLaunchKernelGGL((scan_topk_kernel<DT, NB, NITER, 1>), grid, dim3(256), lds, st, a.rows, a.n, a.dpad, a.qn, a.nq, a.k, a.row_base, a.partial, a.stride_q);
     else
-        hipLaunchKernelGGL((scan_topk_kernel<DT, NB, NITER, 2>), grid, dim3(256), lds, st, rows, n, dpad, qn, nq, k, row_base, partial, stride_q);
+        hipLaunchKernelGGL((scan_topk_kernel<DT, NB, NITER, 2>), grid, dim3(256), lds, st, a.rows, a.n, a.dpad, a.qn, a.nq, a.k, a.row_base, a.partial, a.stride_q);
 }
 
 template <int DT, int NB>
-int launch_scan_niter(int niter, int slots, dim3 grid, size_t lds, hipStream_t st, const void* rows, int64_t n, int dpad,
-                      const float* qn, int nq, int k, uint32_t row_base, u64* partial, int64_t stride_q) {
+int launch_scan_niter(int niter, int slots, dim3 grid, size_t lds, hipStream_t st, const ScanArgs& a) {
     switch (niter) {
-        case 1: launch_scan_slots<DT, NB, 1>(slots, grid, lds, st, rows, n, dpad, qn, nq, k, row_base, partial, stride_q); break;
-        case 2: launch_scan_slots<DT, NB, 2>(slots, grid, lds, st, rows, n, dpad, qn, nq, k, row_base, partial, stride_q); break;
-        case 3: launch_scan_slots<DT, NB, 3>(slots, grid, lds, st, rows, n, dpad, qn, nq, k, row_base, partial, stride_q); break;
-        case 4: launch_scan_slots<DT, NB, 4>(slots, grid, lds, st, rows, n, dpad, qn, nq, k, row_base, partial, stride_q); break;
+        case 1: launch_scan_slots<DT, NB, 1>(slots, grid, lds, st, a); break;
+        case 2: launch_scan_slots<DT, NB, 2>(slots, grid, lds, st, a); break;
+        case 3: launch_scan_slots<DT, NB, 3>(slots, grid, lds, st, a); break;
+        case 4: launch_scan_slots<DT, NB, 4>(slots, grid, lds, st, a); break;
         default: return fail(CODD_KNN_ENOTSUP, "row too wide for the scan kernel%s");
     }
     return CODD_KNN_OK;
 }
 
 template <int DT>
-int launch_scan_nb(int nb, int niter, int slots, dim3 grid, hipStream_t st, const void* rows, int64_t n, int dpad,
-                   const float* qn, int nq, int k, uint32_t row_base, u64* partial, int64_t stride_q) {
+int launch_scan_nb(int nb, int niter, int slots, dim3 grid, hipStream_t st, const ScanArgs& a) {
     const size_t lds = (size_t)4 * nb * slots * kWave * sizeof(u64);
     switch (nb) {
-        case 1: return launch_scan_niter<DT, 1>(niter, slots, grid, lds, st, rows, n, dpad, qn, nq, k, row_base, partial, stride_q);
-        case 4: return launch_scan_niter<DT, 4>(niter, slots, grid, lds, st, rows, n, dpad, qn, nq, k, row_base, partial, stride_q);
-        case 8: return launch_scan_niter<DT, 8>(niter, slots, grid, lds, st, rows, n, dpad, qn, nq, k, row_base, partial, stride_q);
+        case 1: return launch_scan_niter<DT, 1>(niter, slots, grid, lds, st, a);
+        case 4: return launch_scan_niter<DT, 4>(niter, slots, grid, lds, st, a);
+        case 8: return launch_scan_niter<DT, 8>(niter, slots, grid, lds, st, a);
         default: return fail(CODD_KNN_EINVAL, "bad query group%s");
     }
 }
 
-int launch_merge(const u64* in, int B, int64_t m, int k, u64* out_keys, float* out_dist, int64_t* out_rows, hipStream_t st) {
+int launch_merge(const u64* in, int B, int64_t m, int64_t in_stride, int k, u64* out_keys, float* out_dist, int64_t* out_rows,
+                 hipStream_t st) {
     if (k <= 64)
-        hipLaunchKernelGGL(merge_keys_kernel<1>, dim3(B), dim3(256), 0, st, in, m, k, out_keys, out_dist, out_rows);
+        hipLaunchKernelGGL(merge_keys_kernel<1>, dim3(B), dim3(256), 0, st, in, m, in_stride, k, out_keys, out_dist, out_rows);
     else
-        hipLaunchKernelGGL(merge_keys_kernel<2>, dim3(B), dim3(256), 0, st, in, m, k, out_keys, out_dist, out_rows);
+        hipLaunchKernelGGL(merge_keys_kernel<2>, dim3(B), dim3(256), 0, st, in, m, in_stride, k, out_keys, out_dist, out_rows);
     HIP_TRY(hipGetLastError());
     return CODD_KNN_OK;
 }
 
-// the whole shard-local search: normalise queries, scan in groups of <= 8 queries, merge.
+int scan_geometry(const codd_knn_index* ix, int64_t n, int* niter, int64_t* blocks) {
+    const int nchunks = ix->dpad / elems_per_chunk(ix->dtype);
+    *niter = (nchunks + kWave - 1) / kWave;
+    if (*niter > 4) return fail(CODD_KNN_ENOTSUP, "dim too large for this dtype (f32 <= 1024, bf16/f16 <= 2048)%s");
+    const int64_t ngroups = (n + 3) / 4;
+    int64_t b = (ngroups + 3) / 4;
+    const int64_t cap_blocks = (int64_t)ix->num_cus * ix->scan_blocks_per_cu;
+    if (b > cap_blocks) b = cap_blocks;
+    if (b < 1) b = 1;
+    *blocks = b;
+    return CODD_KNN_OK;
+}
+
+// exact scan of `nqueries` dense normalised queries -> keys_out[nqueries][k]
+int exact_scan(codd_knn_index* ix, const float* qn, int nqueries, int k, uint32_t row_base, u64* keys_out, float* dist_out,
+               int64_t* rows_out, hipStream_t st) {
+    const int64_t n = ix->count;
+    int niter;
+    int64_t blocks;
+    int rc = scan_geometry(ix, n, &niter, &blocks);
+    if (rc != 0) return rc;
+    ix->stat_last_scan_blocks = blocks;
+    const int slots = k <= 64 ? 1 : 2;
+    const int64_t stride_q = blocks * k;
+    if ((rc = ensure_buf(&ix->partial, &ix->partial_cap, (int64_t)nqueries * stride_q)) != 0) return rc;
+    for (int q0 = 0; q0 < nqueries; q0 += 8) {
+        const int nq = nqueries - q0 < 8 ? nqueries - q0 : 8;
+        const int nb = nq == 1 ? 1 : (nq <= 4 ? 4 : 8);
+        ScanArgs a{ix->rows, n, ix->dpad, qn + (int64_t)q0 * ix->dpad, nq, k, row_base, ix->partial + (int64_t)q0 * stride_q, stride_q};
+        const dim3 grid((unsigned)blocks);
+        {
+            EvScope ev(ix, EV_SCAN, st);
+            switch (ix->dtype) {
+                case DT_F32: rc = launch_scan_nb<DT_F32>(nb, niter, slots, grid, st, a); break;
+                case DT_BF16: rc = launch_scan_nb<DT_BF16>(nb, niter, slots, grid, st, a); break;
+                case DT_F16: rc = launch_scan_nb<DT_F16>(nb, niter, slots, grid, st, a); break;
+                default: rc = fail(CODD_KNN_EINVAL, "unknown dtype%s");
+            }
+        }
+        if (rc != 0) return rc;
+        HIP_TRY(hipGetLastError());
+        ix->stat_scan_launches++;
+    }
+    return launch_merge(ix->partial, nqueries, stride_q, stride_q, k, keys_out, dist_out, rows_out, st);
+}
+
+// ---- filter path -----------------------------------------------------------------------------
+
+float filter_eps(const codd_knn_index* ix) {
+    // |approx - exact| <= (2^-8 + 2^-16) |q||c| for bf16-rounded q and c (2^-9 each, Cauchy-Schwarz),
+    // 2^-9 when the stored rows already are bf16; + 1e-4 for the two fp32 accumulations; unit norms.
+    const float rounding = ix->dtype == DT_BF16 ? 0.001953125f : 0.00392151f;
+    return (rounding + 1.0e-4f) * 1.001f;
+}
+
+template <int DT, int NITER>
+void launch_finalize_slots(int slots, int B, hipStream_t st, const codd_knn_index* ix, const float* qn, int k, float two_eps,
+                           uint32_t row_base, u64* out_keys) {
+    FilterCtl* c = ix->ctl;
+    if (slots == 1)
+        hipLaunchKernelGGL((finalize_kernel<DT, NITER, 1>), dim3(B), dim3(256), 0, st, ix->rows, ix->dpad, qn, ix->hits, c->hit_cnt,
+                           ix->hit_cap_q, c->flags, k, two_eps, row_base, out_keys, &c->fb_count, c->fb_list, c->stats);
+    else
+        hipLaunchKernelGGL((finalize_kernel<DT, NITER, 2>), dim3(B), dim3(256), 0, st, ix->rows, ix->dpad, qn, ix->hits, c->hit_cnt,
+                           ix->hit_cap_q, c->flags, k, two_eps, row_base, out_keys, &c->fb_count, c->fb_list, c->stats);
+}
+
+template <int DT>
+int launch_finalize(int niter, int slots, int B, hipStream_t st, const codd_knn_index* ix, const float* qn, int k, float two_eps,
+                    uint32_t row_base, u64* out_keys) {
+    switch (niter) {
+        case 1: launch_finalize_slots<DT, 1>(slots, B, st, ix, qn, k, two_eps, row_base, out_keys); break;
+        case 2: launch_finalize_slots<DT, 2>(slots, B, st, ix, qn, k, two_eps, row_base, out_keys); break;
+        case 3: launch_finalize_slots<DT, 3>(slots, B, st, ix, qn, k, two_eps, row_base, out_keys); break;
+        case 4: launch_finalize_slots<DT, 4>(slots, B, st, ix, qn, k, two_eps, row_base, out_keys); break;
+        default: return fail(CODD_KNN_ENOTSUP, "row too wide for the finalize kernel%s");
+    }
+    HIP_TRY(hipGetLastError());
+    return CODD_KNN_OK;
+}
+
+size_t filter_lds_bytes(int mode) {
+    return 65536 + 320 * 4 + (mode == MODE_FILTER ? (size_t)kHitCap * 12 : 0);
+}
+
+int ensure_filter_workspace(codd_knn_index* ix) {
+    int rc;
+    if ((rc = ensure_buf(&ix->qfrag, &ix->qfrag_cap, (int64_t)kTileQ * (ix->dpad / 8))) != 0) return rc;
+    if ((rc = ensure_buf(&ix->bucket_max, &ix->bucket_cap, (int64_t)ix->sample_tiles * kTileQ)) != 0) return rc;
+    if ((rc = ensure_buf(&ix->hits, &ix->hits_cap, (int64_t)kTileQ * ix->hit_cap_q)) != 0) return rc;
+    if (!ix->thr) HIP_TRY(hipMalloc((void**)&ix->thr, kTileQ * sizeof(float)));
+    if (!ix->ctl) HIP_TRY(hipMalloc((void**)&ix->ctl, sizeof(FilterCtl)));
+    if (!ix->ctl_host) HIP_TRY(hipHostMalloc((void**)&ix->ctl_host, sizeof(FilterCtl), hipHostMallocDefault));
+    static bool attr_set = false;  // dynamic LDS above 64 KiB needs the opt-in once per process
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_filter_kernel<MODE_FILTER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter_lds_bytes(MODE_FILTER)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_filter_kernel<MODE_SAMPLE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter_lds_bytes(MODE_SAMPLE)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_filter_kernel<MODE_DUMP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter_lds_bytes(MODE_DUMP)));
+        attr_set = true;
+    }
+    return CODD_KNN_OK;
+}
+
+// one pass of <= 256 queries through sample -> threshold -> filter -> finalize (+ exact fallback)
+int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row_base, u64* keys_out, hipStream_t st) {
+    const int64_t n = ix->count;
+    const int nsteps = ix->dpad / 64;
+    const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
+    const int slots = k <= 64 ? 1 : 2;
+    const float eps = filter_eps(ix);
+    int rc;
+    ix->stat_filter_passes++;
+
+    hipLaunchKernelGGL(qfrag_kernel, dim3((kTileQ * (ix->dpad / 8) + 255) / 256), dim3(256), 0, st, qn, nq, ix->dpad, ix->qfrag);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(ix->ctl, 0, sizeof(FilterCtl), st));
+
+    // sample: every `stride`-th tile, at most sample_tiles of them
+    const int64_t ts = ntiles < ix->sample_tiles ? ntiles : ix->sample_tiles;
+    const int64_t stride = ntiles / ts;
+    {
+        EvScope ev(ix, EV_SAMPLE, st);
+        const int64_t g = ts < ix->num_cus ? ts : ix->num_cus;
+        hipLaunchKernelGGL(gemm_filter_kernel<MODE_SAMPLE>, dim3((unsigned)g), dim3(kFilterThreads), filter_lds_bytes(MODE_SAMPLE), st,
+                           ix->shadow, ix->qfrag, n, nsteps, ts, stride, nullptr, ix->bucket_max, nullptr, nullptr, 0, nullptr, nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    if (slots == 1)
+        hipLaunchKernelGGL(select_thr_kernel<1>, dim3(kTileQ), dim3(64), 0, st, ix->bucket_max, ts, nq, k, 2.0f * eps, ix->thr);
+    else
+        hipLaunchKernelGGL(select_thr_kernel<2>, dim3(kTileQ), dim3(64), 0, st, ix->bucket_max, ts, nq, k, 2.0f * eps, ix->thr);
+    HIP_TRY(hipGetLastError());
+    {
+        EvScope ev(ix, EV_FILTER, st);
+        const int64_t g = ntiles < ix->num_cus ? ntiles : ix->num_cus;
+        hipLaunchKernelGGL(gemm_filter_kernel<MODE_FILTER>, dim3((unsigned)g), dim3(kFilterThreads), filter_lds_bytes(MODE_FILTER), st,
+                           ix->shadow, ix->qfrag, n, nsteps, ntiles, (int64_t)1, ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt,
+                           ix->hit_cap_q, ix->ctl->flags, nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    const int nchunks = ix->dpad / elems_per_chunk(ix->dtype);
+    const int niter = (nchunks + kWave - 1) / kWave;
+    {
+        EvScope ev(ix, EV_FINALIZE, st);
+        switch (ix->dtype) {
+            case DT_F32: rc = launch_finalize<DT_F32>(niter, slots, nq, st, ix, qn, k, 2.0f * eps, row_base, keys_out); break;
+            case DT_BF16: rc = launch_finalize<DT_BF16>(niter, slots, nq, st, ix, qn, k, 2.0f * eps, row_base, keys_out); break;
+            default: rc = launch_finalize<DT_F16>(niter, slots, nq, st, ix, qn, k, 2.0f * eps, row_base, keys_out); break;
+        }
+    }
+    if (rc != 0) return rc;
+
+    // the only host round trip of the path: did any query ask for the exact fallback?
+    HIP_TRY(hipMemcpyAsync(ix->ctl_host, ix->ctl, sizeof(FilterCtl), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    ix->stat_hits += ix->ctl_host->stats[0];
+    ix->stat_survivors += ix->ctl_host->stats[1];
+    const int nfb = (int)ix->ctl_host->fb_count;
+    if (nfb > 0) {
+        ix->stat_fallback_queries += nfb;
+        if ((rc = ensure_buf(&ix->qn_fb, &ix->qn_fb_cap, (int64_t)kTileQ * ix->dpad)) != 0) return rc;
+        if ((rc = ensure_buf(&ix->keys_fb, &ix->keys_fb_cap, (int64_t)kTileQ * CODD_KNN_MAX_K)) != 0) return rc;
+        hipLaunchKernelGGL(gather_queries_kernel, dim3(nfb), dim3(256), 0, st, qn, ix->ctl->fb_list, nfb, ix->dpad, ix->qn_fb);
+        HIP_TRY(hipGetLastError());
+        if ((rc = exact_scan(ix, ix->qn_fb, nfb, k, row_base, ix->keys_fb, nullptr, nullptr, st)) != 0) return rc;
+        hipLaunchKernelGGL(scatter_keys_kernel, dim3(nfb), dim3(128), 0, st, ix->keys_fb, ix->ctl->fb_list, nfb, k, keys_out);
+        HIP_TRY(hipGetLastError());
+    }
+    return CODD_KNN_OK;
+}
+
+bool filter_applies(const codd_knn_index* ix, int B, int k) {
+    // the thresholds come from the k-th largest of the sampled tile maxima: need comfortably more tiles than k
+    const int64_t ntiles = (ix->count + kTileRows - 1) / kTileRows;
+    const int64_t ts = ntiles < ix->sample_tiles ? ntiles : ix->sample_tiles;
+    return ix->filter_enabled && ix->all_normalized && ix->shadow && ix->count >= ix->filter_min_rows &&
+           B >= ix->filter_min_batch && ts >= 2 * (int64_t)k;
+}
+
+// the whole shard-local search: normalise queries, then filter passes or exact scans, keys out.
 int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint32_t row_base, u64* out_keys,
                 float* out_dist, int64_t* out_rows, hipStream_t st) {
     if (!ix) return fail(CODD_KNN_EINVAL, "null index%s");
@@ -463,63 +693,33 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
     DeviceGuard guard(ix->device);
     ix->stat_searches++;
     const int64_t n = ix->count;
-    const int E = elems_per_chunk(ix->dtype);
-    const int nchunks = ix->dpad / E;
-    const int niter = (nchunks + kWave - 1) / kWave;
-    if (niter > 4) return fail(CODD_KNN_ENOTSUP, "dim too large for this dtype (f32 <= 1024, bf16/f16 <= 2048)%s");
-    const int slots = k <= 64 ? 1 : 2;
-
-    // grid: enough waves to cover the row groups, capped at a few blocks per CU (grid-stride)
-    const int64_t ngroups = (n + 3) / 4;
-    int64_t blocks = (ngroups + 3) / 4;
-    const int64_t cap_blocks = (int64_t)ix->num_cus * ix->scan_blocks_per_cu;
-    if (blocks > cap_blocks) blocks = cap_blocks;
-    if (blocks < 1) blocks = 1;
-    ix->stat_last_scan_blocks = blocks;
-
     int rc;
     if ((rc = ensure_buf(&ix->qn, &ix->qn_cap, (int64_t)B * ix->dpad)) != 0) return rc;
-    const int64_t stride_q = blocks * k;
-    if ((rc = ensure_buf(&ix->partial, &ix->partial_cap, (int64_t)B * stride_q)) != 0) return rc;
-
-    if ((rc = launch_normalize(DT_F32, dev_queries, B, ix->dim, ix->dpad, 1, nullptr, 0, ix->qn, st)) != 0) return rc;
+    if ((rc = ensure_buf(&ix->keys_tmp, &ix->keys_tmp_cap, (int64_t)B * k)) != 0) return rc;
+    if ((rc = launch_normalize(DT_F32, dev_queries, B, ix->dim, ix->dpad, 1, nullptr, 0, ix->qn, nullptr, st)) != 0) return rc;
 
     if (n == 0) {
         // nothing stored: all-empty result (chromadb returns {"ids": [[]], ...})
-        HIP_TRY(hipMemsetAsync(ix->partial, 0, (size_t)B * sizeof(u64), st));
-        return launch_merge(ix->partial, B, 1, k, out_keys, out_dist, out_rows, st);
-    }
-
-    for (int q0 = 0; q0 < B; q0 += 8) {
-        const int nq = B - q0 < 8 ? B - q0 : 8;
-        const int nb = nq == 1 ? 1 : (nq <= 4 ? 4 : 8);
-        const float* qn = ix->qn + (int64_t)q0 * ix->dpad;
-        u64* part = ix->partial + (int64_t)q0 * stride_q;
-        const dim3 grid((unsigned)blocks);
-        const bool timed = ix->profile && 2 * (ix->ev_used + 1) <= (int)ix->ev.size();
-        if (timed) HIP_TRY(hipEventRecord(ix->ev[2 * ix->ev_used], st));
-        switch (ix->dtype) {
-            case DT_F32: rc = launch_scan_nb<DT_F32>(nb, niter, slots, grid, st, ix->rows, n, ix->dpad, qn, nq, k, row_base, part, stride_q); break;
-            case DT_BF16: rc = launch_scan_nb<DT_BF16>(nb, niter, slots, grid, st, ix->rows, n, ix->dpad, qn, nq, k, row_base, part, stride_q); break;
-            case DT_F16: rc = launch_scan_nb<DT_F16>(nb, niter, slots, grid, st, ix->rows, n, ix->dpad, qn, nq, k, row_base, part, stride_q); break;
-            default: rc = fail(CODD_KNN_EINVAL, "unknown dtype%s");
+        HIP_TRY(hipMemsetAsync(ix->keys_tmp, 0, (size_t)B * k * sizeof(u64), st));
+    } else if (filter_applies(ix, B, k)) {
+        if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
+        for (int q0 = 0; q0 < B; q0 += kTileQ) {
+            const int nq = B - q0 < kTileQ ? B - q0 : kTileQ;
+            if ((rc = filter_pass(ix, ix->qn + (int64_t)q0 * ix->dpad, nq, k, row_base, ix->keys_tmp + (int64_t)q0 * k, st)) != 0) return rc;
         }
-        if (rc != 0) return rc;
-        HIP_TRY(hipGetLastError());
-        ix->stat_scan_launches++;
-        if (timed) {
-            HIP_TRY(hipEventRecord(ix->ev[2 * ix->ev_used + 1], st));
-            ix->ev_used++;
-        }
+    } else {
+        // small batches: the per-block partials merge straight into the caller's buffers
+        return exact_scan(ix, ix->qn, B, k, row_base, out_keys, out_dist, out_rows, st);
     }
-    return launch_merge(ix->partial, B, stride_q, k, out_keys, out_dist, out_rows, st);
+    // unpack (m == k: the merge kernel is the identity on a sorted list)
+    return launch_merge(ix->keys_tmp, B, k, k, k, out_keys, out_dist, out_rows, st);
 }
 
 }  // namespace
 
 extern "C" {
 
-const char* codd_knn_version(void) { return "codd_knn 0.1.0 gfx950"; }
+const char* codd_knn_version(void) { return "codd_knn 0.2.0 gfx950"; }
 const char* codd_knn_last_error(void) { return g_err; }
 
 int codd_knn_create(codd_knn_index** out, int device, int dim, int dtype, int metric) {
@@ -551,10 +751,11 @@ int codd_knn_destroy(codd_knn_index* ix) {
     if (!ix) return CODD_KNN_OK;
     DeviceGuard guard(ix->device);
     (void)hipDeviceSynchronize();
-    if (ix->rows) (void)hipFree(ix->rows);
-    if (ix->qn) (void)hipFree(ix->qn);
-    if (ix->partial) (void)hipFree(ix->partial);
-    if (ix->keys_tmp) (void)hipFree(ix->keys_tmp);
+    void* bufs[] = {ix->rows, ix->shadow, ix->qn, ix->partial, ix->keys_tmp, ix->qfrag, ix->thr, ix->bucket_max,
+                    ix->hits, ix->ctl, ix->qn_fb, ix->keys_fb};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (ix->ctl_host) (void)hipHostFree(ix->ctl_host);
     for (hipEvent_t e : ix->ev) (void)hipEventDestroy(e);
     delete ix;
     return CODD_KNN_OK;
@@ -566,21 +767,7 @@ int codd_knn_reserve(codd_knn_index* ix, int64_t rows) {
     DeviceGuard guard(ix->device);
     if (rows <= ix->capacity) return CODD_KNN_OK;
     HIP_TRY(hipDeviceSynchronize());
-    // exact growth: the caller states the final size (288 GB of HBM is the only limit)
-    void* fresh = nullptr;
-    const size_t row_bytes = (size_t)ix->dpad * elem_size(ix->dtype);
-    HIP_TRY(hipMalloc(&fresh, (size_t)rows * row_bytes));
-    if (ix->rows && ix->count > 0) {
-        hipError_t e = hipMemcpy(fresh, ix->rows, (size_t)ix->count * row_bytes, hipMemcpyDeviceToDevice);
-        if (e != hipSuccess) {
-            (void)hipFree(fresh);
-            return fail(CODD_KNN_EDEVICE, "row copy on growth failed: %s", hipGetErrorString(e));
-        }
-    }
-    if (ix->rows) (void)hipFree(ix->rows);
-    ix->rows = fresh;
-    ix->capacity = rows;
-    return CODD_KNN_OK;
+    return grow_rows(ix, rows, /*exact=*/true);  // the caller states the final size (288 GB of HBM is the only limit)
 }
 
 int codd_knn_upsert_host(codd_knn_index* ix, const int64_t* host_slots, const float* host_vecs, int64_t n, int normalize) {
@@ -593,7 +780,7 @@ int codd_knn_upsert_host(codd_knn_index* ix, const int64_t* host_slots, const fl
     }
     DeviceGuard guard(ix->device);
     HIP_TRY(hipDeviceSynchronize());
-    int rc = ensure_rows(ix, max_slot + 1);
+    int rc = grow_rows(ix, max_slot + 1, /*exact=*/false);
     if (rc != 0) return rc;
     // stage in bounded pieces (<= 64 MiB of vectors per piece)
     const int64_t piece = (int64_t)(64ll << 20) / ((int64_t)ix->dim * 4) + 1;
@@ -614,12 +801,15 @@ int codd_knn_upsert_host(codd_knn_index* ix, const int64_t* host_slots, const fl
             rc = fail(CODD_KNN_EDEVICE, "staging copy failed: %s", hipGetErrorString(e));
             break;
         }
-        rc = launch_normalize(ix->dtype, dvec, m, ix->dim, ix->dpad, normalize, dslot, 0, ix->rows, nullptr);
+        rc = launch_normalize(ix->dtype, dvec, m, ix->dim, ix->dpad, normalize, dslot, 0, ix->rows, reinterpret_cast<uint2*>(ix->shadow), nullptr);
         if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = fail(CODD_KNN_EDEVICE, "ingest kernel failed%s");
     }
     (void)hipFree(dvec);
     (void)hipFree(dslot);
-    if (rc == 0 && max_slot + 1 > ix->count) ix->count = max_slot + 1;
+    if (rc == 0) {
+        if (max_slot + 1 > ix->count) ix->count = max_slot + 1;
+        if (!normalize) ix->all_normalized = false;
+    }
     return rc;
 }
 
@@ -630,12 +820,14 @@ int codd_knn_upsert_device(codd_knn_index* ix, int64_t first_slot, const float* 
     DeviceGuard guard(ix->device);
     if (first_slot + n > ix->capacity) {
         HIP_TRY(hipDeviceSynchronize());
-        int rc = ensure_rows(ix, first_slot + n);
+        int rc = grow_rows(ix, first_slot + n, /*exact=*/false);
         if (rc != 0) return rc;
     }
-    int rc = launch_normalize(ix->dtype, dev_vecs, n, ix->dim, ix->dpad, normalize, nullptr, first_slot, ix->rows, (hipStream_t)stream);
+    int rc = launch_normalize(ix->dtype, dev_vecs, n, ix->dim, ix->dpad, normalize, nullptr, first_slot, ix->rows,
+                              reinterpret_cast<uint2*>(ix->shadow), (hipStream_t)stream);
     if (rc != 0) return rc;
     if (first_slot + n > ix->count) ix->count = first_slot + n;
+    if (!normalize) ix->all_normalized = false;
     return CODD_KNN_OK;
 }
 
@@ -678,7 +870,25 @@ int codd_knn_merge_keys(int device, const uint64_t* dev_keys_in, int B, int m, i
                         int64_t* dev_rows, void* stream) {
     if (!dev_keys_in || B < 1 || m < 1 || k < 1 || k > CODD_KNN_MAX_K) return fail(CODD_KNN_EINVAL, "bad merge arguments%s");
     DeviceGuard guard(device);
-    return launch_merge((const u64*)dev_keys_in, B, m, k, (u64*)dev_keys_out, dev_dist, dev_rows, (hipStream_t)stream);
+    return launch_merge((const u64*)dev_keys_in, B, m, m, k, (u64*)dev_keys_out, dev_dist, dev_rows, (hipStream_t)stream);
+}
+
+int codd_knn_debug_filter_scores(codd_knn_index* ix, const float* dev_queries, int B, float* dev_scores, void* stream) {
+    if (!ix || !dev_queries || !dev_scores || B < 1 || B > kTileQ) return fail(CODD_KNN_EINVAL, "bad debug arguments%s");
+    if (ix->count < 1 || !ix->shadow) return fail(CODD_KNN_EINVAL, "empty index%s");
+    DeviceGuard guard(ix->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = ensure_buf(&ix->qn, &ix->qn_cap, (int64_t)B * ix->dpad)) != 0) return rc;
+    if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
+    if ((rc = launch_normalize(DT_F32, dev_queries, B, ix->dim, ix->dpad, 1, nullptr, 0, ix->qn, nullptr, st)) != 0) return rc;
+    hipLaunchKernelGGL(qfrag_kernel, dim3((kTileQ * (ix->dpad / 8) + 255) / 256), dim3(256), 0, st, ix->qn, B, ix->dpad, ix->qfrag);
+    const int64_t ntiles = (ix->count + kTileRows - 1) / kTileRows;
+    const int64_t g = ntiles < ix->num_cus ? ntiles : ix->num_cus;
+    hipLaunchKernelGGL(gemm_filter_kernel<MODE_DUMP>, dim3((unsigned)g), dim3(kFilterThreads), filter_lds_bytes(MODE_DUMP), st, ix->shadow,
+                       ix->qfrag, ix->count, ix->dpad / 64, ntiles, (int64_t)1, nullptr, nullptr, nullptr, nullptr, 0, nullptr, dev_scores);
+    HIP_TRY(hipGetLastError());
+    return CODD_KNN_OK;
 }
 
 int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {
@@ -686,6 +896,19 @@ int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {
     if (strcmp(key, "scan_blocks_per_cu") == 0) {
         if (value < 1 || value > 8) return fail(CODD_KNN_EINVAL, "scan_blocks_per_cu must be in [1,8]%s");
         ix->scan_blocks_per_cu = (int)value;
+        return CODD_KNN_OK;
+    }
+    if (strcmp(key, "filter") == 0) { ix->filter_enabled = value != 0; return CODD_KNN_OK; }
+    if (strcmp(key, "filter_min_rows") == 0) { ix->filter_min_rows = value < 1 ? 1 : value; return CODD_KNN_OK; }
+    if (strcmp(key, "filter_min_batch") == 0) { ix->filter_min_batch = value < 1 ? 1 : (int)value; return CODD_KNN_OK; }
+    if (strcmp(key, "sample_tiles") == 0) {
+        if (value < 1 || value > 65536) return fail(CODD_KNN_EINVAL, "sample_tiles must be in [1,65536]%s");
+        ix->sample_tiles = (int)value;
+        return CODD_KNN_OK;
+    }
+    if (strcmp(key, "hit_cap") == 0) {
+        if (value < 16 || value > (1 << 20)) return fail(CODD_KNN_EINVAL, "hit_cap must be in [16,2^20]%s");
+        ix->hit_cap_q = (int)value;
         return CODD_KNN_OK;
     }
     if (strcmp(key, "profile") == 0) {
@@ -697,6 +920,7 @@ int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {
             HIP_TRY(hipEventCreate(&e));
             ix->ev.push_back(e);
         }
+        ix->ev_kind.assign(ix->ev.size() / 2, 0);
         ix->profile = value > 0;
         ix->ev_used = 0;
         return CODD_KNN_OK;
@@ -706,28 +930,42 @@ int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {
 
 int codd_knn_get_stat(const codd_knn_index* ix, const char* key, int64_t* out) {
     if (!ix || !key || !out) return fail(CODD_KNN_EINVAL, "bad stat arguments%s");
-    if (strcmp(key, "searches") == 0) *out = ix->stat_searches;
-    else if (strcmp(key, "scan_launches") == 0) *out = ix->stat_scan_launches;
-    else if (strcmp(key, "last_scan_blocks") == 0) *out = ix->stat_last_scan_blocks;
-    else if (strcmp(key, "scan_events") == 0) *out = ix->ev_used;
-    else if (strcmp(key, "scan_time_ns") == 0) {
-        // sum of the recorded scan launches' durations; synchronises on the last stop event
+    // "time_ns:<kernel>" / "events:<kernel>" with kernel in {scan, filter, sample, finalize}
+    const bool want_time = strncmp(key, "time_ns:", 8) == 0, want_events = strncmp(key, "events:", 7) == 0;
+    if (want_time || want_events) {
+        const char* name = key + (want_time ? 8 : 7);
+        int kind = -1;
+        for (int i = 0; i < EV_KINDS; ++i)
+            if (strcmp(name, kEvNames[i]) == 0) kind = i;
+        if (kind < 0) return fail(CODD_KNN_EINVAL, "unknown kernel name in stat: %s", key);
         double total_ms = 0.0;
+        int64_t events = 0;
         if (ix->ev_used > 0) {
             DeviceGuard guard(ix->device);
             HIP_TRY(hipEventSynchronize(ix->ev[2 * ix->ev_used - 1]));
             for (int i = 0; i < ix->ev_used; ++i) {
+                if (ix->ev_kind[i] != kind) continue;
                 float ms = 0.0f;
                 HIP_TRY(hipEventElapsedTime(&ms, ix->ev[2 * i], ix->ev[2 * i + 1]));
                 total_ms += ms;
+                events++;
             }
         }
-        *out = (int64_t)(total_ms * 1e6);
+        *out = want_time ? (int64_t)(total_ms * 1e6) : events;
+        return CODD_KNN_OK;
     }
+    if (strcmp(key, "searches") == 0) *out = ix->stat_searches;
+    else if (strcmp(key, "scan_launches") == 0) *out = ix->stat_scan_launches;
+    else if (strcmp(key, "last_scan_blocks") == 0) *out = ix->stat_last_scan_blocks;
+    else if (strcmp(key, "filter_passes") == 0) *out = ix->stat_filter_passes;
+    else if (strcmp(key, "fallback_queries") == 0) *out = ix->stat_fallback_queries;
+    else if (strcmp(key, "filter_hits") == 0) *out = ix->stat_hits;
+    else if (strcmp(key, "filter_survivors") == 0) *out = ix->stat_survivors;
     else if (strcmp(key, "capacity_rows") == 0) *out = ix->capacity;
     else if (strcmp(key, "num_cus") == 0) *out = ix->num_cus;
     else if (strcmp(key, "device_bytes") == 0)
-        *out = ix->capacity * (int64_t)ix->dpad * (int64_t)elem_size(ix->dtype) + ix->qn_cap * 4 + ix->partial_cap * 8 + ix->keys_tmp_cap * 8;
+        *out = ix->capacity * (int64_t)ix->dpad * (int64_t)elem_size(ix->dtype) + ix->shadow_rows * (int64_t)ix->dpad * 2 +
+               ix->qn_cap * 4 + ix->partial_cap * 8 + ix->keys_tmp_cap * 8 + ix->hits_cap * 8 + ix->bucket_cap * 4 + ix->qfrag_cap * 16;
     else return fail(CODD_KNN_EINVAL, "unknown stat: %s", key);
     return CODD_KNN_OK;
 }

@@ -1,0 +1,456 @@
+// filter_gemm.h — the large-batch leg of the search: a bf16 MFMA GEMM that never materialises the
+// B x N score matrix.  It FILTERS: for every query it emits the rows whose approximate score
+// clears a per-query threshold that provably keeps every true top-k row; the
+// survivors are re-scored exactly (canonical fp32) by finalize_kernel.
+//
+// Data layout (both operands are stored in MFMA-fragment order, so every wave-level load is one
+// contiguous 1 KiB piece and LDS reads are conflict-free without a swizzle):
+//
+//   shadow (bf16 copy of the corpus, written at ingest), in 16-byte pieces of 8 elements:
+//       piece[((block*nsteps + s)*4 + kk)*64 + (h*32 + r)] = C[row = 32*block + r][k = 64s + 32h + 8kk + 0..7]
+//   qfrag (bf16 query block, written by qfrag_kernel per search):
+//       piece[((s*8 + nb)*4 + kk)*64 + (h*32 + c)]         = Q[query = 32*nb + c][k = 64s + 32h + 8kk + 0..7]
+//
+// One v_mfma_f32_32x32x16_bf16 consumes, per lane (r|c = lane&31, h = lane>>5), exactly one such
+// piece of each operand; the k order inside an instruction is permuted identically on both sides,
+// which a dot product does not notice.
+//
+// Workgroup = 8 waves = one tile of 256 corpus rows x 256 queries, K-step 64:
+//   * wave w owns corpus rows [32w, 32w+32) of the tile and ALL 256 queries: 8 accumulator blocks
+//     of 32x32 (128 VGPRs).  Its corpus fragments go HBM -> registers directly (each corpus byte
+//     enters the CU once, is used by one wave: no LDS round trip), three K-steps deep in a
+//     register ring so ~12 KiB per wave stays in flight;
+//   * the query K-slice (32 KiB, L2-resident, shared by the 8 waves) is double-buffered in LDS,
+//     staged through registers (issue early, write late) so that every load in the kernel is an
+//     ordinary counted load and __syncthreads() stays a bare s_barrier;
+//   * one barrier per K-step; 32 MFMAs + 32 ds_read_b128 per wave per K-step.
+#pragma once
+#include "row_traits.h"
+#include "wave_topk.h"
+
+namespace codd {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kTileRows = 256;
+constexpr int kTileQ = 256;
+constexpr int kFilterThreads = 512;
+constexpr int kStagePieces = 2048;  // 16-byte pieces of one query K-slice (256 q x 64 k bf16 = 32 KiB)
+constexpr int kHitCap = 4096;       // per-workgroup LDS hit list (entries of 3 dwords)
+constexpr int kRing = 3;            // corpus-fragment register ring (K-steps)
+constexpr int kPrefetch = 2;        // K-steps the corpus loads run ahead
+
+enum { MODE_FILTER = 0, MODE_SAMPLE = 1, MODE_DUMP = 2 };
+
+// flags[] words shared with the host
+enum { FLAG_WG_OVERFLOW = 0, FLAG_NEED_FALLBACK = 1, FLAG_WORDS = 4 };
+
+__host__ __device__ inline int64_t shadow_piece_index(int64_t row, int c8, int nsteps) {
+    const int64_t block = row >> 5;
+    const int r = (int)(row & 31);
+    const int s = c8 >> 3, h = (c8 >> 2) & 1, kk = c8 & 3;
+    return ((block * nsteps + s) * 4 + kk) * 64 + (h * 32 + r);
+}
+__host__ __device__ inline int64_t qfrag_piece_index(int q, int c8) {
+    const int nb = q >> 5, c = q & 31;
+    const int s = c8 >> 3, h = (c8 >> 2) & 1, kk = c8 & 3;
+    return (((int64_t)s * 8 + nb) * 4 + kk) * 64 + (h * 32 + c);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    uint32_t a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a = ((a & 0x7fffffffu) > 0x7f800000u) ? ((a >> 16) | 0x0040u) : ((a + 0x7fffu + ((a >> 16) & 1u)) >> 16);
+    b = ((b & 0x7fffffffu) > 0x7f800000u) ? ((b >> 16) | 0x0040u) : ((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
+    return (a & 0xffffu) | (b << 16);
+}
+
+// qn: [B][dpad] fp32 normalised queries -> qfrag pieces (queries >= B are zero).  One thread per piece.
+__global__ __launch_bounds__(256) void qfrag_kernel(const float* __restrict__ qn, int B, int dpad, uint4* __restrict__ qfrag) {
+    const int npieces = kTileQ * (dpad >> 3);
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= npieces) return;
+    const int q = idx / (dpad >> 3), c8 = idx % (dpad >> 3);
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (q < B) {
+        const float4* p = reinterpret_cast<const float4*>(qn + (int64_t)q * dpad + c8 * 8);
+        const float4 a = p[0], b = p[1];
+        v = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+    }
+    qfrag[qfrag_piece_index(q, c8)] = v;
+}
+
+// append a workgroup's LDS hit list (entries: score bits, row, query) to the per-query global lists
+__device__ __forceinline__ void flush_hits(const unsigned* lds_hits, unsigned m, int tid, u64* __restrict__ hits,
+                                           unsigned* __restrict__ hit_cnt, int cap_q) {
+    for (unsigned e = tid; e < m; e += kFilterThreads) {
+        const float v = __uint_as_float(lds_hits[e * 3 + 0]);
+        const unsigned row = lds_hits[e * 3 + 1], q = lds_hits[e * 3 + 2];
+        const unsigned slot = atomicAdd(&hit_cnt[q], 1u);
+        if (slot < (unsigned)cap_q) hits[(int64_t)q * cap_q + slot] = make_key(v, row);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// gemm_filter_kernel<MODE>
+//   MODE_FILTER: every (query, row) with approx score >= thr[query] is appended to hits[query][]
+//   MODE_SAMPLE: per (tile, query) the maximum approx score is written to bucket_max[tile][query]
+//   MODE_DUMP  : all scores to dump[query][row] (diagnostics / layout tests, small n only)
+// Run-tile u (0 <= u < ntiles_run) is corpus tile u*tile_stride; workgroup b takes u = b, b+G, ...
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void gemm_filter_kernel(
+    const uint4* __restrict__ shadow, const uint4* __restrict__ qfrag, int64_t n, int nsteps, int64_t ntiles_run,
+    int64_t tile_stride, const float* __restrict__ thr, float* __restrict__ bucket_max, u64* __restrict__ hits,
+    unsigned* __restrict__ hit_cnt, int cap_q, unsigned* __restrict__ flags, float* __restrict__ dump) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint4* ldsQ = reinterpret_cast<uint4*>(smem);                    // 2 x 32 KiB
+    unsigned* lds_w = reinterpret_cast<unsigned*>(smem + 65536);     // [0..255] thr / bucket max, [256] hit count
+    unsigned* lds_hits = lds_w + 320;                                // kHitCap x 3 dwords (FILTER only)
+
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+
+    const int64_t G = gridDim.x;
+    const int64_t my_tiles = ntiles_run > (int64_t)blockIdx.x ? (ntiles_run - blockIdx.x + G - 1) / G : 0;
+    const int T = (int)(my_tiles * nsteps);  // K-steps of this workgroup (< 2^30: rows < 2^32, nsteps <= 64)
+    if (T == 0) return;
+
+    if (MODE == MODE_FILTER) {
+        if (tid < 256) lds_w[tid] = __float_as_uint(thr[tid]);
+        if (tid == 256) lds_w[256] = 0u;
+    } else if (MODE == MODE_SAMPLE) {
+        if (tid < 256) lds_w[tid] = 0u;
+    }
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nb][i] = 0.0f;
+
+    // load cursor (runs kPrefetch steps ahead of the compute cursor)
+    int64_t l_u = blockIdx.x;  // run-tile ordinal
+    int l_s = 0;
+    // always issues its 4 loads (a conditional load would make hipcc's vmcnt bookkeeping assume the
+    // worst at every join): past the last step the cursor simply stays on the last valid slice
+    int l_left = T;
+    auto load_a = [&](uint4(&dst)[4]) {
+        const int64_t block = l_u * tile_stride * 8 + wave;
+        const uint4* p = shadow + ((block * nsteps + l_s) * 4) * 64 + lane;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) dst[kk] = p[kk * 64];
+        if (--l_left > 0) {
+            if (++l_s == nsteps) { l_s = 0; l_u += G; }
+        }
+    };
+
+    uint4 ring[kRing][4];
+#pragma unroll
+    for (int i = 0; i < kPrefetch; ++i) load_a(ring[i]);
+
+    // stage the first query slice
+    {
+        uint4 qreg[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qreg[i] = qfrag[tid + i * 512];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ldsQ[tid + i * 512] = qreg[i];
+    }
+    __syncthreads();
+
+    int64_t c_u = blockIdx.x;  // compute cursor
+    int c_s = 0;
+    // T is walked in whole rings: the (at most kRing-1) padding steps past T recompute the last slice
+    // into accumulators nobody reads (`live` gates every side effect), which keeps the loop free of
+    // early exits and lets every load stay unconditional
+    for (int t0 = 0; t0 < T; t0 += kRing) {
+#pragma unroll
+        for (int i = 0; i < kRing; ++i) {
+            const int t = t0 + i;
+            const bool live = t < T;
+            // next query slice: issue now, write to LDS after the MFMAs (on the very last step this
+            // re-stages slice 0 into the idle buffer, which nobody reads)
+            uint4 qreg0, qreg1, qreg2, qreg3;
+            {
+                const int s_next = c_s + 1 == nsteps ? 0 : c_s + 1;
+                const uint4* src = qfrag + (int64_t)s_next * kStagePieces + tid;
+                qreg0 = src[0]; qreg1 = src[512]; qreg2 = src[1024]; qreg3 = src[1536];
+            }
+            // corpus fragments for step t+2 AFTER the query loads: vmcnt retires in order, so the
+            // end-of-step wait for the (L2-served) query slice must not sit behind these HBM loads
+            load_a(ring[(i + kPrefetch) % kRing]);
+            const uint4* qs = ldsQ + (t & 1) * kStagePieces + lane;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8 a = __builtin_bit_cast(bf16x8, ring[i][kk]);
+#pragma unroll
+                for (int nb = 0; nb < 8; ++nb) {
+                    const bf16x8 b = __builtin_bit_cast(bf16x8, qs[(nb * 4 + kk) * 64]);
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nb], 0, 0, 0);
+                }
+            }
+            // pin the step's shape: all 8 global loads (4 corpus, 4 query) first so they fly under the
+            // MFMAs; at most a few query fragments live (4 LDS reads up front, then one per MFMA);
+            // the LDS writes of the next query slice last
+            __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int g = 0; g < 28; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);
+            {
+                uint4* dstq = ldsQ + ((t + 1) & 1) * kStagePieces + tid;
+                dstq[0] = qreg0; dstq[512] = qreg1; dstq[1024] = qreg2; dstq[1536] = qreg3;
+            }
+
+            if (live && c_s == nsteps - 1) {
+                // ---- tile epilogue ----
+                const int64_t tile = c_u * tile_stride;
+                const int64_t row0 = tile * kTileRows + wave * 32 + 4 * h;  // + (reg&3) + 8*(reg>>2)
+                const bool ragged = (tile + 1) * kTileRows > n;
+                if (MODE == MODE_FILTER) {
+#pragma unroll
+                    for (int nb = 0; nb < 8; ++nb) {
+                        const float th = __uint_as_float(lds_w[nb * 32 + c]);
+                        float m = acc[nb][0];
+#pragma unroll
+                        for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[nb][r]);
+                        if (__any(m >= th)) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float v = acc[nb][r];
+                                const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
+                                if (v >= th && row < n) {
+                                    const unsigned slot = atomicAdd(&lds_w[256], 1u);
+                                    if (slot < (unsigned)kHitCap) {
+                                        lds_hits[slot * 3 + 0] = __float_as_uint(v);
+                                        lds_hits[slot * 3 + 1] = (unsigned)row;
+                                        lds_hits[slot * 3 + 2] = (unsigned)(nb * 32 + c);
+                                    } else {
+                                        // list full (> kHitCap/2 hits inside ONE tile): this query's candidates
+                                        // are incomplete -> push its counter past the cap so that finalize
+                                        // sends exactly this query to the exact-scan fallback
+                                        atomicAdd(&hit_cnt[nb * 32 + c], (unsigned)cap_q + 1u);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                } else if (MODE == MODE_SAMPLE) {
+#pragma unroll
+                    for (int nb = 0; nb < 8; ++nb) {
+                        float m = -INFINITY;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
+                            const float v = (!ragged || row < n) ? acc[nb][r] : -INFINITY;
+                            m = fmaxf(m, v);
+                        }
+                        atomicMax(&lds_w[nb * 32 + c], ord_f32(m));
+                    }
+                } else {
+#pragma unroll
+                    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
+                            if (row < n) dump[(int64_t)(nb * 32 + c) * n + row] = acc[nb][r];
+                        }
+                }
+#pragma unroll
+                for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+            }
+            __syncthreads();
+            if (MODE == MODE_FILTER && live && c_s == nsteps - 1) {
+                // tile boundary: empty the workgroup's hit list once it is half full
+                const unsigned cnt = lds_w[256];
+                __syncthreads();  // everyone has read cnt before the next epilogue can move it
+                if (cnt > (unsigned)(kHitCap / 2)) {
+                    flush_hits(lds_hits, cnt < (unsigned)kHitCap ? cnt : (unsigned)kHitCap, tid, hits, hit_cnt, cap_q);
+                    __syncthreads();
+                    if (tid == 0) lds_w[256] = 0u;
+                    __syncthreads();
+                }
+            }
+            if (MODE == MODE_SAMPLE && live && c_s == nsteps - 1) {
+                // all 8 waves have folded this tile into lds_w: publish and reset (next fold is >= 1 barrier away
+                // only when nsteps > 1; with nsteps == 1 the extra barrier below keeps it safe)
+                if (tid < 256) {
+                    bucket_max[c_u * 256 + tid] = unord_f32(lds_w[tid]);
+                    lds_w[tid] = 0u;
+                }
+                if (nsteps == 1) __syncthreads();
+            }
+            if (++c_s == nsteps) { c_s = 0; c_u += G; }
+        }
+    }
+
+    if (MODE == MODE_FILTER) {
+        const unsigned cnt = lds_w[256];  // stable: the loop ended on a barrier
+        if (cnt > (unsigned)kHitCap && tid == 0) atomicOr(&flags[FLAG_WG_OVERFLOW], 1u);  // statistics only
+        flush_hits(lds_hits, cnt < (unsigned)kHitCap ? cnt : (unsigned)kHitCap, tid, hits, hit_cnt, cap_q);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// select_thr_kernel: one wave per query.  thr[q] = (k-th largest bucket maximum) - slack, a score
+// every true top-k row's approximation provably clears; -inf when fewer than k buckets exist;
+// +inf for padding queries (q >= B) so they never hit.
+// ---------------------------------------------------------------------------------------------
+template <int SLOTS>
+__global__ __launch_bounds__(64) void select_thr_kernel(const float* __restrict__ bucket_max, int64_t nbuckets, int B, int k,
+                                                        float slack, float* __restrict__ thr) {
+    const int q = blockIdx.x, lane = lane_id();
+    if (q >= B) {
+        if (lane == 0) thr[q] = INFINITY;
+        return;
+    }
+    WaveTopK<SLOTS> L;
+    L.init();
+    for (int64_t i0 = 0; i0 < nbuckets; i0 += kWave) {
+        const int64_t i = i0 + lane;
+        const u64 cand = i < nbuckets ? make_key(bucket_max[i * 256 + q], (uint32_t)i) : 0ull;
+        L.offer_lanes(cand, k, lane);
+    }
+    if (lane == 0) thr[q] = L.thr ? key_score(L.thr) - slack : -INFINITY;
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize_kernel<DT, NITER, SLOTS>: one workgroup (4 waves) per query.
+//   1. a_k = k-th largest APPROXIMATE score among the query's hits;
+//   2. survivors = hits with approx >= a_k - 2*eps  (no other row can reach the exact top-k);
+//   3. exact canonical fp32 score of every survivor (one wave per row, same expression as the scan);
+//   4. top-k of the exact keys -> out_keys[q] (global rows: row_base added).
+// A query whose hit list overflowed (or any workgroup list did) is queued for the exact-scan
+// fallback instead: fb_list[atomicAdd(fb_count)] = q.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSurvivorCap = 2048;
+
+template <int DT, int NITER, int SLOTS>
+__global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ rows_, int dpad, const float* __restrict__ qn,
+                                                       const u64* __restrict__ hits, const unsigned* __restrict__ hit_cnt,
+                                                       int cap_q, unsigned* __restrict__ flags, int k, float two_eps,
+                                                       uint32_t row_base, u64* __restrict__ out_keys,
+                                                       unsigned* __restrict__ fb_count, unsigned* __restrict__ fb_list,
+                                                       unsigned* __restrict__ stats) {
+    typedef RowTraits<DT> RT;
+    constexpr int E = RT::E;
+    __shared__ u64 lds_list[4 * SLOTS * kWave];
+    __shared__ unsigned lds_surv[kSurvivorCap];
+    __shared__ unsigned lds_n;
+    __shared__ float lds_lo;
+
+    const int q = blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned total = hit_cnt[q];
+    const bool overflow = total > (unsigned)cap_q;  // list truncated, or poisoned by a full workgroup list
+    if (overflow) {
+        if (tid == 0) {
+            fb_list[atomicAdd(fb_count, 1u)] = (unsigned)q;
+            atomicOr(&flags[FLAG_NEED_FALLBACK], 1u);
+        }
+        return;
+    }
+    const u64* my = hits + (int64_t)q * cap_q;
+    if (tid == 0) lds_n = 0u;
+
+    // 1. k-th largest approximate key
+    WaveTopK<SLOTS> L;
+    L.init();
+    for (unsigned i0 = wave * kWave; i0 < total; i0 += 256) {
+        const unsigned i = i0 + lane;
+        L.offer_lanes(i < total ? my[i] : 0ull, k, lane);
+    }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) lds_list[(wave * SLOTS + s) * kWave + lane] = L.v[s];
+    __syncthreads();
+    if (wave == 0) {
+        for (int wv = 1; wv < 4; ++wv)
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                u64 cand = lds_list[(wv * SLOTS + s) * kWave + lane];
+                if (s * kWave + lane >= k) cand = 0ull;
+                L.offer_lanes(cand, k, lane);
+            }
+        if (lane == 0) lds_lo = L.thr ? key_score(L.thr) - two_eps : -INFINITY;
+    }
+    __syncthreads();
+    const float lo = lds_lo;
+
+    // 2. survivors
+    for (unsigned i = tid; i < total; i += 256) {
+        const u64 key = my[i];
+        if (key_score(key) >= lo) {
+            const unsigned slot = atomicAdd(&lds_n, 1u);
+            if (slot < (unsigned)kSurvivorCap) lds_surv[slot] = key_row(key);
+        }
+    }
+    __syncthreads();
+    const unsigned ns = lds_n;
+    if (ns > (unsigned)kSurvivorCap) {
+        if (tid == 0) {
+            fb_list[atomicAdd(fb_count, 1u)] = (unsigned)q;
+            atomicOr(&flags[FLAG_NEED_FALLBACK], 1u);
+        }
+        return;
+    }
+    if (tid == 0 && stats) {
+        atomicAdd(&stats[0], total);
+        atomicAdd(&stats[1], ns);
+    }
+
+    // 3. exact canonical scores of the survivors (one wave per row)
+    const int nchunks = dpad / E;
+    float qf[NITER][E];
+#pragma unroll
+    for (int it = 0; it < NITER; ++it) {
+        const int j = lane + kWave * it;
+#pragma unroll
+        for (int e = 0; e < E; ++e) qf[it][e] = j < nchunks ? qn[(int64_t)q * dpad + (int64_t)j * E + e] : 0.0f;
+    }
+    const uint4* base = reinterpret_cast<const uint4*>(rows_);
+    WaveTopK<SLOTS> X;
+    X.init();
+    for (unsigned j = wave; j < ns; j += 4) {
+        const unsigned row = lds_surv[j];
+        const uint4* p = base + (int64_t)row * nchunks + lane;
+        float acc = 0.0f;
+#pragma unroll
+        for (int it = 0; it < NITER; ++it) {
+            uint4 cch = make_uint4(0u, 0u, 0u, 0u);
+            if (lane + kWave * it < nchunks) cch = p[kWave * it];
+            float w[E];
+            RT::widen(cch, w);
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc = __builtin_fmaf(qf[it][e], w[e], acc);
+        }
+        const float s = butterfly_sum(acc);
+        X.offer(make_key(s, row_base + row), k, lane);
+    }
+
+    // 4. merge the four wave lists
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) lds_list[(wave * SLOTS + s) * kWave + lane] = X.v[s];
+    __syncthreads();
+    if (wave != 0) return;
+    for (int wv = 1; wv < 4; ++wv)
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            u64 cand = lds_list[(wv * SLOTS + s) * kWave + lane];
+            if (s * kWave + lane >= k) cand = 0ull;
+            X.offer_lanes(cand, k, lane);
+        }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int rank = s * kWave + lane;
+        if (rank < k) out_keys[(int64_t)q * k + rank] = X.v[s];
+    }
+}
+
+}  // namespace codd

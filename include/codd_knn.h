@@ -114,11 +114,25 @@ int codd_knn_merge_keys(int device, const uint64_t* dev_keys_in, int B, int m, i
                         uint64_t* dev_keys_out, float* dev_dist, int64_t* dev_rows, void* stream);
 
 /*
+ * Diagnostics: the raw approximate (bf16 MFMA) scores of the large-batch filter for B <= 256
+ * queries against every stored row: dev_scores[q * count + row], q < 256 (rows of padding
+ * queries are zero).  Lets tests check the MFMA operand layouts in isolation.
+ */
+int codd_knn_debug_filter_scores(codd_knn_index* index, const float* dev_queries, int B,
+                                 float* dev_scores, void* stream);
+
+/*
  * Tuning / introspection (never needed for correctness).
- *   options: "scan_blocks_per_cu" (1..8); "profile" = N keeps N (start, stop) HIP-event
- *            pairs, one per scan-kernel launch, recorded on the launch stream (0 = off)
- *   stats  : "searches", "scan_launches", "last_scan_blocks", "capacity_rows",
- *            "device_bytes", "num_cus", "scan_events", "scan_time_ns" (syncs on the last event)
+ *   options: "scan_blocks_per_cu" (1..8); "filter" (0/1: MFMA filter path for large batches);
+ *            "filter_min_rows", "filter_min_batch" (when the filter path is taken);
+ *            "sample_tiles" (tiles that set the per-query thresholds), "hit_cap" (per-query
+ *            candidate capacity; overflow falls back to the exact scan);
+ *            "profile" = N keeps N (start, stop) HIP-event pairs, one per heavy-kernel launch,
+ *            recorded on the launch stream (0 = off; resets the log)
+ *   stats  : "searches", "scan_launches", "last_scan_blocks", "filter_passes",
+ *            "fallback_queries", "filter_hits", "filter_survivors", "capacity_rows",
+ *            "device_bytes", "num_cus", and per kernel K in {scan, filter, sample, finalize}:
+ *            "events:K", "time_ns:K" (sum of the recorded launches; syncs on the last event)
  */
 int codd_knn_set_option(codd_knn_index* index, const char* key, int64_t value);
 int codd_knn_get_stat(const codd_knn_index* index, const char* key, int64_t* out);

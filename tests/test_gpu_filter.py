@@ -1,0 +1,164 @@
+"""GPU parity of the large-batch leg: bf16 MFMA filter + exact fp32 re-score (csrc/filter_gemm.h).
+
+The filter is only allowed to change SPEED: final ids and distances must stay bit-identical to
+the canonical CPU oracle, including when its candidate lists overflow and the exact-scan
+fallback takes over."""
+
+import numpy as np
+import pytest
+
+from oracle import knn_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Index():
+    import torch
+
+    assert torch.cuda.is_available()
+    from codd_query_engine_amd.knn_index import DeviceKnnIndex
+
+    return DeviceKnnIndex
+
+
+def build(Index, raw, dtype="f32", force_filter=True):
+    ix = Index(raw.shape[1], dtype=dtype)
+    ix.upsert(np.arange(raw.shape[0], dtype=np.int64), raw)
+    if force_filter:
+        ix.set_option("filter_min_rows", 1)
+        ix.set_option("filter_min_batch", 1)
+    return ix
+
+
+def oracle_answer(raw, q_raw, k, dtype):
+    rows = o.to_storage(o.normalize_rows(raw), dtype)
+    return o.search(rows, dtype, o.normalize_rows(q_raw), k)
+
+
+@pytest.mark.parametrize("n,d,B,dtype", [(1000, 768, 40, "f32"), (300, 128, 256, "f32"), (700, 384, 7, "bf16"), (513, 1024, 33, "f16")])
+def test_mfma_scores_match_bf16_reference(Index, n, d, B, dtype):
+    """Operand layouts: every approximate score equals the dot product of the bf16-rounded stored
+    row and bf16-rounded query (fp32 accumulation order aside)."""
+    rng = np.random.default_rng(n + d)
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    raw[:, 0] += 3.0  # asymmetric data: a transposed or permuted operand cannot pass
+    q = rng.standard_normal((B, d)).astype(np.float32)
+    ix = build(Index, raw, dtype)
+    got = ix.debug_filter_scores(q).cpu().numpy()
+    stored = o.widen(o.to_storage(o.normalize_rows(raw), dtype), dtype)
+    cb = o.widen(o.to_storage(stored, "bf16"), "bf16").astype(np.float64)
+    qb = o.widen(o.to_storage(o.normalize_rows(q), "bf16"), "bf16").astype(np.float64)
+    ref = qb @ cb.T
+    assert got.shape == (256, n)
+    assert np.abs(got[:B] - ref).max() < 2e-5
+    assert not got[B:].any()
+    ix.close()
+
+
+@pytest.mark.parametrize(
+    "n,d,B,k,dtype",
+    [
+        (70_000, 768, 256, 10, "f32"),   # the headline shape, scaled down
+        (33_000, 768, 64, 10, "f32"),
+        (20_001, 384, 17, 5, "f32"),     # ragged last tile, ragged batch
+        (50_000, 768, 300, 10, "f32"),   # two query passes (256 + 44)
+        (60_000, 256, 32, 100, "f32"),   # k = 100 (two list slots)
+        (40_000, 768, 96, 10, "bf16"),
+        (12_000, 1024, 48, 10, "f16"),
+        (5_200, 128, 20, 10, "f32"),     # 21 tiles: barely enough buckets for k = 10
+    ],
+)
+def test_filter_path_is_exact(Index, n, d, B, k, dtype):
+    rng = np.random.default_rng(n + B)
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((B, d)).astype(np.float32)
+    ix = build(Index, raw, dtype)
+    dist, rows = ix.search(q, k)
+    assert ix.stat("filter_passes") == (B + 255) // 256
+    d_ref, i_ref = oracle_answer(raw, q, k, dtype)
+    assert np.array_equal(rows, i_ref)
+    assert np.array_equal(dist, d_ref)
+    assert ix.stat("fallback_queries") == 0, "random data must not need the fallback"
+    assert ix.stat("filter_survivors") < ix.stat("filter_hits") <= B * 8192
+    ix.close()
+
+
+def test_overflow_falls_back_and_stays_exact(Index):
+    """5,000 near-copies of one vector: every one of them clears any sound threshold, the
+    per-query candidate list (shrunk to 64 here) overflows, and the exact scan must take over
+    for the affected queries only."""
+    rng = np.random.default_rng(1)
+    n, d, B, k = 40_000, 256, 24, 10
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    centre = rng.standard_normal(d).astype(np.float32)
+    dup = rng.choice(n, size=5000, replace=False)
+    raw[dup] = centre + 1e-3 * rng.standard_normal((5000, d)).astype(np.float32)
+    q = rng.standard_normal((B, d)).astype(np.float32)
+    q[3] = centre
+    q[11] = centre + 1e-3 * rng.standard_normal(d).astype(np.float32)
+    ix = build(Index, raw)
+    ix.set_option("hit_cap", 64)
+    dist, rows = ix.search(q, k)
+    d_ref, i_ref = oracle_answer(raw, q, k, "f32")
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    assert 2 <= ix.stat("fallback_queries") < B
+    ix.close()
+
+
+def test_ties_resolve_to_lower_row_through_the_filter(Index):
+    rng = np.random.default_rng(2)
+    n, d = 35_000, 768
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    for r in (17, 9000, 20_000, 34_999):
+        raw[r] = raw[5]
+    q = rng.standard_normal((16, d)).astype(np.float32)
+    q[0] = raw[5]
+    ix = build(Index, raw)
+    dist, rows = ix.search(q, 10)
+    assert rows[0, :5].tolist() == [5, 17, 9000, 20_000, 34_999]
+    d_ref, i_ref = oracle_answer(raw, q, 10, "f32")
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    ix.close()
+
+
+def test_filter_and_exact_scan_agree_at_scale(Index):
+    """1M x 768, B=256: the two legs of the engine must return the same bits (the oracle cannot
+    brute-force this size quickly; the exact scan is itself oracle-checked at smaller sizes)."""
+    import torch
+
+    n, d, B, k = 1_000_000, 768, 256, 10
+    g = torch.Generator(device="cuda").manual_seed(7)
+    ix = Index(d)
+    ix.reserve(n)
+    for c in range(4):
+        ix.upsert_device(c * 250_000, torch.randn((250_000, d), generator=g, device="cuda"))
+    q = torch.randn((B, d), generator=g, device="cuda")
+    d_f, r_f = ix.search_tensors(q, k)
+    assert ix.stat("filter_passes") == 1 and ix.stat("fallback_queries") == 0
+    ix.set_option("filter", 0)
+    d_e, r_e = ix.search_tensors(q, k)
+    assert torch.equal(r_f, r_e) and torch.equal(d_f, d_e)
+    ix.close()
+
+
+def test_too_few_tiles_for_k_takes_the_exact_scan(Index):
+    rng = np.random.default_rng(8)
+    raw = rng.standard_normal((9_000, 256)).astype(np.float32)  # 36 tiles < 2 * 100
+    q = rng.standard_normal((32, 256)).astype(np.float32)
+    ix = build(Index, raw)
+    dist, rows = ix.search(q, 100)
+    assert ix.stat("filter_passes") == 0
+    d_ref, i_ref = oracle_answer(raw, q, 100, "f32")
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    ix.close()
+
+
+def test_unnormalised_rows_disable_the_filter(Index):
+    rng = np.random.default_rng(3)
+    raw = rng.standard_normal((40_000, 128)).astype(np.float32)
+    ix = Index(128)
+    ix.upsert(np.arange(40_000, dtype=np.int64), raw, normalize=False)  # caller's own scaling: no unit-norm bound
+    ix.search(rng.standard_normal((32, 128)).astype(np.float32), 5)
+    assert ix.stat("filter_passes") == 0
+    ix.close()
