@@ -42,8 +42,9 @@ def parse_args():
     p.add_argument("--k", type=int, default=10)
     p.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f16"])
     p.add_argument("--latency-iters", type=int, default=30)
-    p.add_argument("--cpu-sample-rows", type=int, default=400_000)
-    p.add_argument("--cpu-sample-queries", type=int, default=32)
+    p.add_argument("--cpu-sample-rows", type=int, default=4_000_000)
+    p.add_argument("--cpu-sample-queries", type=int, default=256)
+    p.add_argument("--cpu-seconds", type=float, default=10.0)
     p.add_argument("--no-cpu-baseline", action="store_true")
     return p.parse_args()
 
@@ -79,18 +80,25 @@ def build_shard(ix, torch, lo, hi, n_total, dim, queries, n_planted_q, k, device
 
 
 def cpu_baseline(ix, args, queries_cpu):
-    """The oracle's all-core fp32 scan (port) on a bounded sample of the same corpus."""
+    """The oracle's all-core fp32 scan (port) on a bounded sample of the same corpus: a short probe
+    sizes the sample so that the timed run is ~10 s of CPU work on whatever host this is."""
     import numpy as np
 
     from oracle import knn_oracle as o
 
-    n = min(args.cpu_sample_rows, ix.count())
-    rows = ix.read_rows(0, n)
-    if ix.dtype != "f32":
-        rows = o.widen(rows, ix.dtype)
     nq = min(args.cpu_sample_queries, queries_cpu.shape[0])
     qn = o.normalize_rows(np.ascontiguousarray(queries_cpu[:nq]))
-    o.search_fast_f32(rows[:1000], qn, args.k)  # page in / warm threads
+    probe_n = min(100_000, ix.count())
+    rows = ix.read_rows(0, probe_n)
+    rows = rows if ix.dtype == "f32" else o.widen(rows, ix.dtype)
+    o.search_fast_f32(rows[:2000], qn, args.k)  # warm the thread pool
+    t0 = time.perf_counter()
+    o.search_fast_f32(rows, qn, args.k)
+    rate = nq * probe_n / max(time.perf_counter() - t0, 1e-6)  # dot products / s
+    n = int(min(ix.count(), args.cpu_sample_rows, max(probe_n, args.cpu_seconds * rate / nq)))
+    if n > probe_n:
+        rows = ix.read_rows(0, n)
+        rows = rows if ix.dtype == "f32" else o.widen(rows, ix.dtype)
     t0 = time.perf_counter()
     o.search_fast_f32(rows, qn, args.k)
     dt = time.perf_counter() - t0
@@ -103,6 +111,19 @@ def cpu_baseline(ix, args, queries_cpu):
         "sample": f"{nq} queries x first {n} rows of the same corpus in {dt:.2f} s, scaled to {args.rows} rows "
                   "(oracle/knn_oracle.c oracle_search_fast_f32, OpenMP; ChromaDB itself is not installable offline)",
     }
+
+
+def measured_traffic(kernel, dtype, dim, n_local):
+    """HBM bytes per launch from the committed PMC pass (profiles/traffic_r1.json), scaled by rows;
+    None when no counter run exists for this kernel/shape."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_r1.json")) as f:
+            t = json.load(f)
+        if t["dim"] != dim:
+            return None
+        return t["bytes_per_row"][kernel][dtype] * n_local
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def main():
@@ -236,7 +257,7 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
-            "traffic": None,
+            "traffic": measured_traffic(dom, args.dtype, d, n_local) if dom else None,
             "algorithmic_bytes_per_launch": algo_bytes_launch,
             "avg_launch_ms": avg_launch_s * 1e3 if avg_launch_s else None,
             "launches_timed": kernels[dom]["launches"] if dom else 0,

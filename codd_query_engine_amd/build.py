@@ -72,6 +72,20 @@ def build(force: bool = False, report: bool = False) -> str:
     return LIB_PATH
 
 
+def build_variant(name: str, defines: dict) -> str:
+    """Compile the same sources with extra -D switches into csrc/libcodd_knn_<name>.so
+    (kernel A/B experiments; load it with CODD_KNN_LIB=<path>)."""
+    out = os.path.join(CSRC, f"libcodd_knn_{name}.so")
+    cmd = [_hipcc(), *HIPCC_FLAGS, "-I", os.path.join(_ROOT, "include"), "-I", CSRC]
+    cmd += [f"-D{k}={v}" for k, v in defines.items()]
+    cmd += ["-o", out, *[os.path.join(CSRC, s) for s in SOURCES]]
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        sys.stderr.write(proc.stdout + proc.stderr)
+        raise RuntimeError(f"hipcc failed building variant {name}")
+    return out
+
+
 def resource_report(remarks: str) -> str:
     """Condense -Rpass-analysis=kernel-resource-usage into one line per kernel."""
     rows, cur = [], {}

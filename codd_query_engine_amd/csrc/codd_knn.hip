@@ -586,7 +586,7 @@ int launch_finalize(int niter, int slots, int B, hipStream_t st, const codd_knn_
 }
 
 size_t filter_lds_bytes(int mode) {
-    return 65536 + 320 * 4 + (mode == MODE_FILTER ? (size_t)kHitCap * 12 : 0);
+    return (size_t)kLdsQBytes + 320 * 4 + (mode == MODE_FILTER ? (size_t)kHitCap * 12 : 0);
 }
 
 int ensure_filter_workspace(codd_knn_index* ix) {

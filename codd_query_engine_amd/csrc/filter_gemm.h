@@ -37,7 +37,37 @@ constexpr int kTileRows = 256;
 constexpr int kTileQ = 256;
 constexpr int kFilterThreads = 512;
 constexpr int kStagePieces = 2048;  // 16-byte pieces of one query K-slice (256 q x 64 k bf16 = 32 KiB)
-constexpr int kHitCap = 4096;       // per-workgroup LDS hit list (entries of 3 dwords)
+// build-time experiment switches (defaults = the shipped configuration)
+#ifndef CODD_QS
+#define CODD_QS 2            // 64-wide query K-slices per LDS stage = K-steps per workgroup barrier
+#endif
+#ifndef CODD_PIN_SCHEDULE
+#define CODD_PIN_SCHEDULE 1  // sched_group_barrier shape of a K-step
+#endif
+#ifndef CODD_MFMA_PRIO
+#define CODD_MFMA_PRIO 0     // s_setprio(1) around the MFMA cluster
+#endif
+#ifndef CODD_NO_EPILOGUE
+#define CODD_NO_EPILOGUE 0   // diagnostic only: skip the threshold test (results are wrong)
+#endif
+#ifndef CODD_EXP_SAME_TILE
+#define CODD_EXP_SAME_TILE 0 // diagnostic only: every step re-reads tile 0 (L2-resident corpus)
+#endif
+#ifndef CODD_EXP_NO_QSTAGE
+#define CODD_EXP_NO_QSTAGE 0 // diagnostic only: no query staging loads / LDS writes
+#endif
+#ifndef CODD_EXP_NB
+#define CODD_EXP_NB 8        // diagnostic only: query blocks actually multiplied (8 = all)
+#endif
+#ifndef CODD_EXP_NO_HITS
+#define CODD_EXP_NO_HITS 0   // diagnostic only: thresholds forced to +inf
+#endif
+#ifndef CODD_EXP_NO_BARRIER
+#define CODD_EXP_NO_BARRIER 0 // diagnostic only: no stage barriers (racy)
+#endif
+constexpr int kQS = CODD_QS;
+constexpr int kLdsQBytes = 2 * kQS * kStagePieces * 16;
+constexpr int kHitCap = kQS == 1 ? 4096 : 2048;  // per-workgroup LDS hit list (entries of 3 dwords)
 constexpr int kRing = 3;            // corpus-fragment register ring (K-steps)
 constexpr int kPrefetch = 2;        // K-steps the corpus loads run ahead
 
@@ -104,9 +134,9 @@ __global__ __launch_bounds__(512, 2) void gemm_filter_kernel(
     int64_t tile_stride, const float* __restrict__ thr, float* __restrict__ bucket_max, u64* __restrict__ hits,
     unsigned* __restrict__ hit_cnt, int cap_q, unsigned* __restrict__ flags, float* __restrict__ dump) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint4* ldsQ = reinterpret_cast<uint4*>(smem);                    // 2 x 32 KiB
-    unsigned* lds_w = reinterpret_cast<unsigned*>(smem + 65536);     // [0..255] thr / bucket max, [256] hit count
-    unsigned* lds_hits = lds_w + 320;                                // kHitCap x 3 dwords (FILTER only)
+    uint4* ldsQ = reinterpret_cast<uint4*>(smem);                        // 2 stages x kQS slices x 32 KiB
+    unsigned* lds_w = reinterpret_cast<unsigned*>(smem + kLdsQBytes);    // [0..255] thr / bucket max, [256] hit count
+    unsigned* lds_hits = lds_w + 320;                                    // kHitCap x 3 dwords (FILTER only)
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -136,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void gemm_filter_kernel(
     // worst at every join): past the last step the cursor simply stays on the last valid slice
     int l_left = T;
     auto load_a = [&](uint4(&dst)[4]) {
-        const int64_t block = l_u * tile_stride * 8 + wave;
+        const int64_t block = (CODD_EXP_SAME_TILE ? 0 : l_u * tile_stride * 8) + wave;
         const uint4* p = shadow + ((block * nsteps + l_s) * 4) * 64 + lane;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) dst[kk] = p[kk * 64];
@@ -149,13 +179,18 @@ __global__ __launch_bounds__(512, 2) void gemm_filter_kernel(
 #pragma unroll
     for (int i = 0; i < kPrefetch; ++i) load_a(ring[i]);
 
-    // stage the first query slice
-    {
-        uint4 qreg[4];
+    // The query operand is a cyclic stream of 64-wide K slices (slice of step t = t mod nsteps),
+    // consumed through LDS stages of kQS slices: stage g holds the slices of steps [g*kQS, (g+1)*kQS).
+    // Stage 0 is filled here; during step t each thread fetches its part of the slice of step t+kQS
+    // and writes it into the other stage after its MFMAs; one barrier per STAGE, not per step.
+    int q_s = 0;  // slice that the next staging load fetches
 #pragma unroll
-        for (int i = 0; i < 4; ++i) qreg[i] = qfrag[tid + i * 512];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ldsQ[tid + i * 512] = qreg[i];
+    for (int sub = 0; sub < kQS; ++sub) {
+        const uint4* src = qfrag + (int64_t)q_s * kStagePieces + tid;
+        uint4* dst = ldsQ + sub * kStagePieces + tid;
+        const uint4 a0 = src[0], a1 = src[512], a2 = src[1024], a3 = src[1536];
+        dst[0] = a0; dst[512] = a1; dst[1024] = a2; dst[1536] = a3;
+        q_s = q_s + 1 == nsteps ? 0 : q_s + 1;
     }
     __syncthreads();
 
@@ -169,45 +204,54 @@ __global__ __launch_bounds__(512, 2) void gemm_filter_kernel(
         for (int i = 0; i < kRing; ++i) {
             const int t = t0 + i;
             const bool live = t < T;
-            // next query slice: issue now, write to LDS after the MFMAs (on the very last step this
-            // re-stages slice 0 into the idle buffer, which nobody reads)
+            const int stage = t / kQS, sub = t % kQS;
+            // query slice of step t+kQS: issue now, write to LDS after the MFMAs
             uint4 qreg0, qreg1, qreg2, qreg3;
             {
-                const int s_next = c_s + 1 == nsteps ? 0 : c_s + 1;
-                const uint4* src = qfrag + (int64_t)s_next * kStagePieces + tid;
-                qreg0 = src[0]; qreg1 = src[512]; qreg2 = src[1024]; qreg3 = src[1536];
+                const uint4* src = qfrag + (int64_t)q_s * kStagePieces + tid;
+                if (!CODD_EXP_NO_QSTAGE) { qreg0 = src[0]; qreg1 = src[512]; qreg2 = src[1024]; qreg3 = src[1536]; }
+                q_s = q_s + 1 == nsteps ? 0 : q_s + 1;
             }
             // corpus fragments for step t+2 AFTER the query loads: vmcnt retires in order, so the
             // end-of-step wait for the (L2-served) query slice must not sit behind these HBM loads
             load_a(ring[(i + kPrefetch) % kRing]);
-            const uint4* qs = ldsQ + (t & 1) * kStagePieces + lane;
+            const uint4* qs = ldsQ + ((stage & 1) * kQS + sub) * kStagePieces + lane;
+#if CODD_MFMA_PRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const bf16x8 a = __builtin_bit_cast(bf16x8, ring[i][kk]);
 #pragma unroll
-                for (int nb = 0; nb < 8; ++nb) {
+                for (int nb = 0; nb < CODD_EXP_NB; ++nb) {
                     const bf16x8 b = __builtin_bit_cast(bf16x8, qs[(nb * 4 + kk) * 64]);
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nb], 0, 0, 0);
                 }
             }
-            // pin the step's shape: all 8 global loads (4 corpus, 4 query) first so they fly under the
+#if CODD_MFMA_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+#if CODD_PIN_SCHEDULE
+            // pin the step's shape: all 8 global loads (4 query, 4 corpus) first so they fly under the
             // MFMAs; at most a few query fragments live (4 LDS reads up front, then one per MFMA);
             // the LDS writes of the next query slice last
-            __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, CODD_EXP_NO_QSTAGE ? 4 : 8, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-            for (int g = 0; g < 28; ++g) {
+            for (int g = 0; g < 4 * CODD_EXP_NB - 4; ++g) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);
+            if (!CODD_EXP_NO_QSTAGE) __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);
+#endif
             {
-                uint4* dstq = ldsQ + ((t + 1) & 1) * kStagePieces + tid;
-                dstq[0] = qreg0; dstq[512] = qreg1; dstq[1024] = qreg2; dstq[1536] = qreg3;
+                uint4* dstq = ldsQ + (((stage + 1) & 1) * kQS + sub) * kStagePieces + tid;
+                if (!CODD_EXP_NO_QSTAGE) { dstq[0] = qreg0; dstq[512] = qreg1; dstq[1024] = qreg2; dstq[1536] = qreg3; }
             }
 
-            if (live && c_s == nsteps - 1) {
+            const bool tile_end = live && c_s == nsteps - 1;
+            if (tile_end && !CODD_NO_EPILOGUE) {
                 // ---- tile epilogue ----
                 const int64_t tile = c_u * tile_stride;
                 const int64_t row0 = tile * kTileRows + wave * 32 + 4 * h;  // + (reg&3) + 8*(reg>>2)
@@ -215,7 +259,7 @@ __global__ __launch_bounds__(512, 2) void gemm_filter_kernel(
                 if (MODE == MODE_FILTER) {
 #pragma unroll
                     for (int nb = 0; nb < 8; ++nb) {
-                        const float th = __uint_as_float(lds_w[nb * 32 + c]);
+                        const float th = CODD_EXP_NO_HITS ? INFINITY : __uint_as_float(lds_w[nb * 32 + c]);
                         float m = acc[nb][0];
 #pragma unroll
                         for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[nb][r]);
@@ -261,14 +305,18 @@ __global__ __launch_bounds__(512, 2) void gemm_filter_kernel(
                             if (row < n) dump[(int64_t)(nb * 32 + c) * n + row] = acc[nb][r];
                         }
                 }
+            }
+            if (tile_end) {
 #pragma unroll
                 for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
             }
-            __syncthreads();
-            if (MODE == MODE_FILTER && live && c_s == nsteps - 1) {
-                // tile boundary: empty the workgroup's hit list once it is half full
+            // stage boundary: the other stage is complete and this one is free to be overwritten.
+            // A tile end synchronises too (its bookkeeping below needs every wave's epilogue done).
+            if ((sub == kQS - 1 && !CODD_EXP_NO_BARRIER) || tile_end) __syncthreads();
+            if (MODE == MODE_FILTER && tile_end) {
+                // empty the workgroup's hit list once it is half full
                 const unsigned cnt = lds_w[256];
                 __syncthreads();  // everyone has read cnt before the next epilogue can move it
                 if (cnt > (unsigned)(kHitCap / 2)) {
@@ -278,21 +326,22 @@ __global__ __launch_bounds__(512, 2) void gemm_filter_kernel(
                     __syncthreads();
                 }
             }
-            if (MODE == MODE_SAMPLE && live && c_s == nsteps - 1) {
-                // all 8 waves have folded this tile into lds_w: publish and reset (next fold is >= 1 barrier away
-                // only when nsteps > 1; with nsteps == 1 the extra barrier below keeps it safe)
+            if (MODE == MODE_SAMPLE && tile_end) {
+                // all 8 waves have folded this tile into lds_w: publish, reset, and fence the reset
+                // against the next tile's fold
                 if (tid < 256) {
                     bucket_max[c_u * 256 + tid] = unord_f32(lds_w[tid]);
                     lds_w[tid] = 0u;
                 }
-                if (nsteps == 1) __syncthreads();
+                __syncthreads();
             }
             if (++c_s == nsteps) { c_s = 0; c_u += G; }
         }
     }
 
     if (MODE == MODE_FILTER) {
-        const unsigned cnt = lds_w[256];  // stable: the loop ended on a barrier
+        __syncthreads();
+        const unsigned cnt = lds_w[256];
         if (cnt > (unsigned)kHitCap && tid == 0) atomicOr(&flags[FLAG_WG_OVERFLOW], 1u);  // statistics only
         flush_hits(lds_hits, cnt < (unsigned)kHitCap ? cnt : (unsigned)kHitCap, tid, hits, hit_cnt, cap_q);
     }

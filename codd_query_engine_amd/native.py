@@ -11,7 +11,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcodd_knn.so")
+# CODD_KNN_LIB selects an alternative build of the SAME source (kernel A/B experiments, scripts/)
+LIB_PATH = os.environ.get("CODD_KNN_LIB") or os.path.join(_HERE, "csrc", "libcodd_knn.so")
 
 DTYPE_CODES = {"f32": 0, "bf16": 1, "f16": 2}
 DTYPE_NAMES = {v: k for k, v in DTYPE_CODES.items()}

@@ -73,8 +73,8 @@ int codd_knn_reserve(codd_knn_index* index, int64_t rows);
  *           slots chosen by the host id-map; a slot may be new (append) or existing
  *           (overwrite).  normalize != 0 scales each vector to unit L2 norm first
  *           (always what the façade asks for; 0 is for callers that already did).
- *           Storage grows as needed.  The host variant stages through pinned memory and
- *           is synchronous; the device variant writes slots [first_slot, first_slot+n).
+ *           Storage grows as needed.  The host variant stages through a bounded device
+ *           buffer and is synchronous; the device variant writes slots [first_slot, first_slot+n).
  */
 int codd_knn_upsert_host(codd_knn_index* index, const int64_t* host_slots, const float* host_vecs,
                          int64_t n, int normalize);
