@@ -299,6 +299,7 @@ struct codd_knn_index {
     // filter path knobs
     int filter_enabled = 1;
     int64_t filter_min_rows = 32768;
+    int64_t filter_min_rows_small = 500000;  // batches below filter_min_batch
     int filter_min_batch = 16;
     int sample_tiles = 1024;
     int hit_cap_q = 8192;
@@ -599,9 +600,14 @@ int ensure_filter_workspace(codd_knn_index* ix) {
     if (!ix->ctl_host) HIP_TRY(hipHostMalloc((void**)&ix->ctl_host, sizeof(FilterCtl), hipHostMallocDefault));
     static bool attr_set = false;  // dynamic LDS above 64 KiB needs the opt-in once per process
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_filter_kernel<MODE_FILTER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter_lds_bytes(MODE_FILTER)));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_filter_kernel<MODE_SAMPLE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter_lds_bytes(MODE_SAMPLE)));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_filter_kernel<MODE_DUMP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter_lds_bytes(MODE_DUMP)));
+        const void* fns[] = {
+            (const void*)&gemm_filter_kernel<MODE_FILTER, 1>, (const void*)&gemm_filter_kernel<MODE_FILTER, 2>,
+            (const void*)&gemm_filter_kernel<MODE_FILTER, 4>, (const void*)&gemm_filter_kernel<MODE_FILTER, 8>,
+            (const void*)&gemm_filter_kernel<MODE_SAMPLE, 1>, (const void*)&gemm_filter_kernel<MODE_SAMPLE, 2>,
+            (const void*)&gemm_filter_kernel<MODE_SAMPLE, 4>, (const void*)&gemm_filter_kernel<MODE_SAMPLE, 8>,
+            (const void*)&gemm_filter_kernel<MODE_DUMP, 8>};
+        for (const void* fn : fns)
+            HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter_lds_bytes(MODE_FILTER)));
         attr_set = true;
     }
     return CODD_KNN_OK;
@@ -624,11 +630,21 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     // sample: every `stride`-th tile, at most sample_tiles of them
     const int64_t ts = ntiles < ix->sample_tiles ? ntiles : ix->sample_tiles;
     const int64_t stride = ntiles / ts;
+    const int nbq = nq <= 32 ? 1 : (nq <= 64 ? 2 : (nq <= 128 ? 4 : 8));  // 32-query blocks the GEMM multiplies
     {
         EvScope ev(ix, EV_SAMPLE, st);
-        const int64_t g = ts < ix->num_cus ? ts : ix->num_cus;
-        hipLaunchKernelGGL(gemm_filter_kernel<MODE_SAMPLE>, dim3((unsigned)g), dim3(kFilterThreads), filter_lds_bytes(MODE_SAMPLE), st,
-                           ix->shadow, ix->qfrag, n, nsteps, ts, stride, nullptr, ix->bucket_max, nullptr, nullptr, 0, nullptr, nullptr);
+        const dim3 g((unsigned)(ts < ix->num_cus ? ts : ix->num_cus)), b(kFilterThreads);
+        const size_t lds = filter_lds_bytes(MODE_SAMPLE);
+#define CODD_LAUNCH_SAMPLE(NBQ)                                                                                              \
+    hipLaunchKernelGGL((gemm_filter_kernel<MODE_SAMPLE, NBQ>), g, b, lds, st, ix->shadow, ix->qfrag, n, nsteps, ts, stride, \
+                       nullptr, ix->bucket_max, nullptr, nullptr, 0, nullptr, nullptr)
+        switch (nbq) {
+            case 1: CODD_LAUNCH_SAMPLE(1); break;
+            case 2: CODD_LAUNCH_SAMPLE(2); break;
+            case 4: CODD_LAUNCH_SAMPLE(4); break;
+            default: CODD_LAUNCH_SAMPLE(8); break;
+        }
+#undef CODD_LAUNCH_SAMPLE
     }
     HIP_TRY(hipGetLastError());
     if (slots == 1)
@@ -638,10 +654,18 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     HIP_TRY(hipGetLastError());
     {
         EvScope ev(ix, EV_FILTER, st);
-        const int64_t g = ntiles < ix->num_cus ? ntiles : ix->num_cus;
-        hipLaunchKernelGGL(gemm_filter_kernel<MODE_FILTER>, dim3((unsigned)g), dim3(kFilterThreads), filter_lds_bytes(MODE_FILTER), st,
-                           ix->shadow, ix->qfrag, n, nsteps, ntiles, (int64_t)1, ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt,
-                           ix->hit_cap_q, ix->ctl->flags, nullptr);
+        const dim3 g((unsigned)(ntiles < ix->num_cus ? ntiles : ix->num_cus)), b(kFilterThreads);
+        const size_t lds = filter_lds_bytes(MODE_FILTER);
+#define CODD_LAUNCH_FILTER(NBQ)                                                                                             \
+    hipLaunchKernelGGL((gemm_filter_kernel<MODE_FILTER, NBQ>), g, b, lds, st, ix->shadow, ix->qfrag, n, nsteps, ntiles,     \
+                       (int64_t)1, ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, nullptr)
+        switch (nbq) {
+            case 1: CODD_LAUNCH_FILTER(1); break;
+            case 2: CODD_LAUNCH_FILTER(2); break;
+            case 4: CODD_LAUNCH_FILTER(4); break;
+            default: CODD_LAUNCH_FILTER(8); break;
+        }
+#undef CODD_LAUNCH_FILTER
     }
     HIP_TRY(hipGetLastError());
     const int nchunks = ix->dpad / elems_per_chunk(ix->dtype);
@@ -679,8 +703,11 @@ bool filter_applies(const codd_knn_index* ix, int B, int k) {
     // the thresholds come from the k-th largest of the sampled tile maxima: need comfortably more tiles than k
     const int64_t ntiles = (ix->count + kTileRows - 1) / kTileRows;
     const int64_t ts = ntiles < ix->sample_tiles ? ntiles : ix->sample_tiles;
-    return ix->filter_enabled && ix->all_normalized && ix->shadow && ix->count >= ix->filter_min_rows &&
-           B >= ix->filter_min_batch && ts >= 2 * (int64_t)k;
+    if (!(ix->filter_enabled && ix->all_normalized && ix->shadow) || ts < 2 * (int64_t)k) return false;
+    // large batches: always worth it past a few tiles per CU; small batches (the single-query latency
+    // point): the bf16 stream halves the bytes, which beats the extra launches from ~0.5M rows on
+    if (B >= ix->filter_min_batch) return ix->count >= ix->filter_min_rows;
+    return ix->count >= ix->filter_min_rows_small;
 }
 
 // the whole shard-local search: normalise queries, then filter passes or exact scans, keys out.
@@ -885,7 +912,7 @@ int codd_knn_debug_filter_scores(codd_knn_index* ix, const float* dev_queries, i
     hipLaunchKernelGGL(qfrag_kernel, dim3((kTileQ * (ix->dpad / 8) + 255) / 256), dim3(256), 0, st, ix->qn, B, ix->dpad, ix->qfrag);
     const int64_t ntiles = (ix->count + kTileRows - 1) / kTileRows;
     const int64_t g = ntiles < ix->num_cus ? ntiles : ix->num_cus;
-    hipLaunchKernelGGL(gemm_filter_kernel<MODE_DUMP>, dim3((unsigned)g), dim3(kFilterThreads), filter_lds_bytes(MODE_DUMP), st, ix->shadow,
+    hipLaunchKernelGGL((gemm_filter_kernel<MODE_DUMP, 8>), dim3((unsigned)g), dim3(kFilterThreads), filter_lds_bytes(MODE_DUMP), st, ix->shadow,
                        ix->qfrag, ix->count, ix->dpad / 64, ntiles, (int64_t)1, nullptr, nullptr, nullptr, nullptr, 0, nullptr, dev_scores);
     HIP_TRY(hipGetLastError());
     return CODD_KNN_OK;
@@ -900,6 +927,7 @@ int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {
     }
     if (strcmp(key, "filter") == 0) { ix->filter_enabled = value != 0; return CODD_KNN_OK; }
     if (strcmp(key, "filter_min_rows") == 0) { ix->filter_min_rows = value < 1 ? 1 : value; return CODD_KNN_OK; }
+    if (strcmp(key, "filter_min_rows_small") == 0) { ix->filter_min_rows_small = value < 1 ? 1 : value; return CODD_KNN_OK; }
     if (strcmp(key, "filter_min_batch") == 0) { ix->filter_min_batch = value < 1 ? 1 : (int)value; return CODD_KNN_OK; }
     if (strcmp(key, "sample_tiles") == 0) {
         if (value < 1 || value > 65536) return fail(CODD_KNN_EINVAL, "sample_tiles must be in [1,65536]%s");

@@ -35,8 +35,14 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int kTileRows = 256;
 constexpr int kTileQ = 256;
-constexpr int kFilterThreads = 512;
 constexpr int kStagePieces = 2048;  // 16-byte pieces of one query K-slice (256 q x 64 k bf16 = 32 KiB)
+#ifndef CODD_RB
+#define CODD_RB 1            // 32-row corpus blocks per wave: 1 -> 8 waves x 256 regs, 2 -> 4 waves x 512 regs
+#endif
+constexpr int kRB = CODD_RB;
+constexpr int kFilterWaves = 8 / kRB;
+constexpr int kFilterThreads = 64 * kFilterWaves;
+constexpr int kQP = kStagePieces / kFilterThreads;  // query-slice pieces each thread stages per K-step
 // build-time experiment switches (defaults = the shipped configuration)
 #ifndef CODD_QS
 #define CODD_QS 2            // 64-wide query K-slices per LDS stage = K-steps per workgroup barrier
@@ -46,6 +52,9 @@ constexpr int kStagePieces = 2048;  // 16-byte pieces of one query K-slice (256 
 #endif
 #ifndef CODD_MFMA_PRIO
 #define CODD_MFMA_PRIO 0     // s_setprio(1) around the MFMA cluster
+#endif
+#ifndef CODD_STATIC_PRIO
+#define CODD_STATIC_PRIO 0   // waves 4..7 (the second wave of every SIMD) run at s_setprio 1 for the whole kernel
 #endif
 #ifndef CODD_NO_EPILOGUE
 #define CODD_NO_EPILOGUE 0   // diagnostic only: skip the threshold test (results are wrong)
@@ -62,14 +71,20 @@ constexpr int kStagePieces = 2048;  // 16-byte pieces of one query K-slice (256 
 #ifndef CODD_EXP_NO_HITS
 #define CODD_EXP_NO_HITS 0   // diagnostic only: thresholds forced to +inf
 #endif
+#ifndef CODD_EXP_NO_LDSREAD
+#define CODD_EXP_NO_LDSREAD 0 // diagnostic only: the query fragment is taken from a register, not from LDS
+#endif
 #ifndef CODD_EXP_NO_BARRIER
 #define CODD_EXP_NO_BARRIER 0 // diagnostic only: no stage barriers (racy)
 #endif
 constexpr int kQS = CODD_QS;
 constexpr int kLdsQBytes = 2 * kQS * kStagePieces * 16;
 constexpr int kHitCap = kQS == 1 ? 4096 : 2048;  // per-workgroup LDS hit list (entries of 3 dwords)
-constexpr int kRing = 3;            // corpus-fragment register ring (K-steps)
-constexpr int kPrefetch = 2;        // K-steps the corpus loads run ahead
+#ifndef CODD_RING
+#define CODD_RING 3
+#endif
+constexpr int kRing = CODD_RING;        // corpus-fragment register ring (K-steps)
+constexpr int kPrefetch = CODD_RING - 1;  // K-steps the corpus loads run ahead
 
 enum { MODE_FILTER = 0, MODE_SAMPLE = 1, MODE_DUMP = 2 };
 
@@ -122,14 +137,15 @@ __device__ __forceinline__ void flush_hits(const unsigned* lds_hits, unsigned m,
 }
 
 // ---------------------------------------------------------------------------------------------
-// gemm_filter_kernel<MODE>
+// gemm_filter_kernel<MODE, NBQ>   (NBQ = 32-query blocks actually multiplied: 1, 2, 4 or 8; a small
+//   batch pays only for its own MFMAs and LDS traffic and the kernel turns into a pure HBM stream)
 //   MODE_FILTER: every (query, row) with approx score >= thr[query] is appended to hits[query][]
 //   MODE_SAMPLE: per (tile, query) the maximum approx score is written to bucket_max[tile][query]
 //   MODE_DUMP  : all scores to dump[query][row] (diagnostics / layout tests, small n only)
 // Run-tile u (0 <= u < ntiles_run) is corpus tile u*tile_stride; workgroup b takes u = b, b+G, ...
 // ---------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(512, 2) void gemm_filter_kernel(
+template <int MODE, int NBQ>
+__global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_kernel(
     const uint4* __restrict__ shadow, const uint4* __restrict__ qfrag, int64_t n, int nsteps, int64_t ntiles_run,
     int64_t tile_stride, const float* __restrict__ thr, float* __restrict__ bucket_max, u64* __restrict__ hits,
     unsigned* __restrict__ hit_cnt, int cap_q, unsigned* __restrict__ flags, float* __restrict__ dump) {
@@ -148,16 +164,20 @@ __global__ __launch_bounds__(512, 2) void gemm_filter_kernel(
 
     if (MODE == MODE_FILTER) {
         if (tid < 256) lds_w[tid] = __float_as_uint(thr[tid]);
-        if (tid == 256) lds_w[256] = 0u;
+        if (tid == 0) lds_w[256] = 0u;
     } else if (MODE == MODE_SAMPLE) {
         if (tid < 256) lds_w[tid] = 0u;
     }
 
-    f32x16 acc[8];
+    constexpr int kSP = NBQ * 256;  // 16-byte pieces of a query slice that are actually staged
+    constexpr int kQPn = kSP / kFilterThreads > 0 ? kSP / kFilterThreads : 1;
+    f32x16 acc[kRB][NBQ];
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb)
+    for (int rb = 0; rb < kRB; ++rb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[nb][i] = 0.0f;
+        for (int nb = 0; nb < NBQ; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rb][nb][i] = 0.0f;
 
     // load cursor (runs kPrefetch steps ahead of the compute cursor)
     int64_t l_u = blockIdx.x;  // run-tile ordinal
@@ -165,17 +185,20 @@ __global__ __launch_bounds__(512, 2) void gemm_filter_kernel(
     // always issues its 4 loads (a conditional load would make hipcc's vmcnt bookkeeping assume the
     // worst at every join): past the last step the cursor simply stays on the last valid slice
     int l_left = T;
-    auto load_a = [&](uint4(&dst)[4]) {
-        const int64_t block = (CODD_EXP_SAME_TILE ? 0 : l_u * tile_stride * 8) + wave;
-        const uint4* p = shadow + ((block * nsteps + l_s) * 4) * 64 + lane;
+    auto load_a = [&](uint4(&dst)[kRB][4]) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) dst[kk] = p[kk * 64];
+        for (int rb = 0; rb < kRB; ++rb) {
+            const int64_t block = (CODD_EXP_SAME_TILE ? 0 : l_u * tile_stride * 8) + wave * kRB + rb;
+            const uint4* p = shadow + ((block * nsteps + l_s) * 4) * 64 + lane;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) dst[rb][kk] = p[kk * 64];
+        }
         if (--l_left > 0) {
             if (++l_s == nsteps) { l_s = 0; l_u += G; }
         }
     };
 
-    uint4 ring[kRing][4];
+    uint4 ring[kRing][kRB][4];
 #pragma unroll
     for (int i = 0; i < kPrefetch; ++i) load_a(ring[i]);
 
@@ -184,16 +207,28 @@ __global__ __launch_bounds__(512, 2) void gemm_filter_kernel(
     // Stage 0 is filled here; during step t each thread fetches its part of the slice of step t+kQS
     // and writes it into the other stage after its MFMAs; one barrier per STAGE, not per step.
     int q_s = 0;  // slice that the next staging load fetches
+    // every thread stages (loads are unconditional, see load_a); when the slice has fewer pieces than
+    // threads, two threads copy the same piece to the same place
+    const int stid = kSP >= kFilterThreads ? tid : tid % kSP;
 #pragma unroll
     for (int sub = 0; sub < kQS; ++sub) {
-        const uint4* src = qfrag + (int64_t)q_s * kStagePieces + tid;
-        uint4* dst = ldsQ + sub * kStagePieces + tid;
-        const uint4 a0 = src[0], a1 = src[512], a2 = src[1024], a3 = src[1536];
-        dst[0] = a0; dst[512] = a1; dst[1024] = a2; dst[1536] = a3;
+        const uint4* src = qfrag + (int64_t)q_s * kStagePieces + stid;
+        uint4* dst = ldsQ + sub * kStagePieces + stid;
+        uint4 tmp[kQPn];
+#pragma unroll
+        for (int j = 0; j < kQPn; ++j) tmp[j] = src[j * kFilterThreads];
+#pragma unroll
+        for (int j = 0; j < kQPn; ++j) dst[j * kFilterThreads] = tmp[j];
         q_s = q_s + 1 == nsteps ? 0 : q_s + 1;
     }
     __syncthreads();
 
+#if CODD_STATIC_PRIO
+    // the two waves of a SIMD otherwise run in lockstep (same barriers, age-based arbitration) and do
+    // their non-MFMA work at the same time; a standing priority makes one of them take the matrix pipe
+    // for its whole cluster while the other loads/stages, which staggers them by half a step
+    if (__builtin_amdgcn_readfirstlane(tid) >= kFilterThreads / 2) __builtin_amdgcn_s_setprio(CODD_STATIC_PRIO);
+#endif
     int64_t c_u = blockIdx.x;  // compute cursor
     int c_s = 0;
     // T is walked in whole rings: the (at most kRing-1) padding steps past T recompute the last slice
@@ -206,10 +241,13 @@ __global__ __launch_bounds__(512, 2) void gemm_filter_kernel(
             const bool live = t < T;
             const int stage = t / kQS, sub = t % kQS;
             // query slice of step t+kQS: issue now, write to LDS after the MFMAs
-            uint4 qreg0, qreg1, qreg2, qreg3;
+            uint4 qreg[kQPn];
             {
-                const uint4* src = qfrag + (int64_t)q_s * kStagePieces + tid;
-                if (!CODD_EXP_NO_QSTAGE) { qreg0 = src[0]; qreg1 = src[512]; qreg2 = src[1024]; qreg3 = src[1536]; }
+                const uint4* src = qfrag + (int64_t)q_s * kStagePieces + stid;
+                if (!CODD_EXP_NO_QSTAGE) {
+#pragma unroll
+                    for (int j = 0; j < kQPn; ++j) qreg[j] = src[j * kFilterThreads];
+                }
                 q_s = q_s + 1 == nsteps ? 0 : q_s + 1;
             }
             // corpus fragments for step t+2 AFTER the query loads: vmcnt retires in order, so the
@@ -221,52 +259,61 @@ __global__ __launch_bounds__(512, 2) void gemm_filter_kernel(
 #endif
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const bf16x8 a = __builtin_bit_cast(bf16x8, ring[i][kk]);
 #pragma unroll
-                for (int nb = 0; nb < CODD_EXP_NB; ++nb) {
-                    const bf16x8 b = __builtin_bit_cast(bf16x8, qs[(nb * 4 + kk) * 64]);
-                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nb], 0, 0, 0);
+                for (int nb = 0; nb < (CODD_EXP_NB < NBQ ? CODD_EXP_NB : NBQ); ++nb) {
+                    const bf16x8 b = CODD_EXP_NO_LDSREAD ? __builtin_bit_cast(bf16x8, ring[i][0][(kk + nb) & 3])
+                                                         : __builtin_bit_cast(bf16x8, qs[(nb * 4 + kk) * 64]);
+#pragma unroll
+                    for (int rb = 0; rb < kRB; ++rb)
+                        acc[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[i][rb][kk]), b,
+                                                                              acc[rb][nb], 0, 0, 0);
                 }
             }
 #if CODD_MFMA_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
-#if CODD_PIN_SCHEDULE
+#if CODD_PIN_SCHEDULE && !CODD_EXP_NO_LDSREAD
             // pin the step's shape: all 8 global loads (4 query, 4 corpus) first so they fly under the
             // MFMAs; at most a few query fragments live (4 LDS reads up front, then one per MFMA);
             // the LDS writes of the next query slice last
-            __builtin_amdgcn_sched_group_barrier(0x020, CODD_EXP_NO_QSTAGE ? 4 : 8, 0);
+            constexpr int kNbRun = CODD_EXP_NB < NBQ ? CODD_EXP_NB : NBQ;
+            __builtin_amdgcn_sched_group_barrier(0x020, 4 * kRB + (CODD_EXP_NO_QSTAGE ? 0 : kQPn), 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-            for (int g = 0; g < 4 * CODD_EXP_NB - 4; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            for (int g = 0; g < 4 * kNbRun - 4; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, kRB, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            if (!CODD_EXP_NO_QSTAGE) __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * kRB, 0);
+            if (!CODD_EXP_NO_QSTAGE) __builtin_amdgcn_sched_group_barrier(0x200, kQPn, 0);
 #endif
             {
-                uint4* dstq = ldsQ + (((stage + 1) & 1) * kQS + sub) * kStagePieces + tid;
-                if (!CODD_EXP_NO_QSTAGE) { dstq[0] = qreg0; dstq[512] = qreg1; dstq[1024] = qreg2; dstq[1536] = qreg3; }
+                uint4* dstq = ldsQ + (((stage + 1) & 1) * kQS + sub) * kStagePieces + stid;
+                if (!CODD_EXP_NO_QSTAGE) {
+#pragma unroll
+                    for (int j = 0; j < kQPn; ++j) dstq[j * kFilterThreads] = qreg[j];
+                }
             }
 
             const bool tile_end = live && c_s == nsteps - 1;
             if (tile_end && !CODD_NO_EPILOGUE) {
                 // ---- tile epilogue ----
                 const int64_t tile = c_u * tile_stride;
-                const int64_t row0 = tile * kTileRows + wave * 32 + 4 * h;  // + (reg&3) + 8*(reg>>2)
                 const bool ragged = (tile + 1) * kTileRows > n;
+#pragma unroll
+                for (int rb = 0; rb < kRB; ++rb) {
+                const int64_t row0 = tile * kTileRows + (wave * kRB + rb) * 32 + 4 * h;  // + (reg&3) + 8*(reg>>2)
                 if (MODE == MODE_FILTER) {
 #pragma unroll
-                    for (int nb = 0; nb < 8; ++nb) {
+                    for (int nb = 0; nb < NBQ; ++nb) {
                         const float th = CODD_EXP_NO_HITS ? INFINITY : __uint_as_float(lds_w[nb * 32 + c]);
-                        float m = acc[nb][0];
+                        float m = acc[rb][nb][0];
 #pragma unroll
-                        for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[nb][r]);
+                        for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rb][nb][r]);
                         if (__any(m >= th)) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
-                                const float v = acc[nb][r];
+                                const float v = acc[rb][nb][r];
                                 const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
                                 if (v >= th && row < n) {
                                     const unsigned slot = atomicAdd(&lds_w[256], 1u);
@@ -286,31 +333,34 @@ __global__ __launch_bounds__(512, 2) void gemm_filter_kernel(
                     }
                 } else if (MODE == MODE_SAMPLE) {
 #pragma unroll
-                    for (int nb = 0; nb < 8; ++nb) {
+                    for (int nb = 0; nb < NBQ; ++nb) {
                         float m = -INFINITY;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
-                            const float v = (!ragged || row < n) ? acc[nb][r] : -INFINITY;
+                            const float v = (!ragged || row < n) ? acc[rb][nb][r] : -INFINITY;
                             m = fmaxf(m, v);
                         }
                         atomicMax(&lds_w[nb * 32 + c], ord_f32(m));
                     }
                 } else {
 #pragma unroll
-                    for (int nb = 0; nb < 8; ++nb)
+                    for (int nb = 0; nb < NBQ; ++nb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
-                            if (row < n) dump[(int64_t)(nb * 32 + c) * n + row] = acc[nb][r];
+                            if (row < n) dump[(int64_t)(nb * 32 + c) * n + row] = acc[rb][nb][r];
                         }
                 }
+            }  // rb
             }
             if (tile_end) {
 #pragma unroll
-                for (int nb = 0; nb < 8; ++nb)
+                for (int rb = 0; rb < kRB; ++rb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.0f;
+                    for (int nb = 0; nb < NBQ; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[rb][nb][r] = 0.0f;
             }
             // stage boundary: the other stage is complete and this one is free to be overwritten.
             // A tile end synchronises too (its bookkeeping below needs every wave's epilogue done).

@@ -124,7 +124,8 @@ int codd_knn_debug_filter_scores(codd_knn_index* index, const float* dev_queries
 /*
  * Tuning / introspection (never needed for correctness).
  *   options: "scan_blocks_per_cu" (1..8); "filter" (0/1: MFMA filter path for large batches);
- *            "filter_min_rows", "filter_min_batch" (when the filter path is taken);
+ *            "filter_min_batch" (16), "filter_min_rows" (32768, batches >= filter_min_batch),
+ *            "filter_min_rows_small" (500000, smaller batches): when the filter path is taken;
  *            "sample_tiles" (tiles that set the per-query thresholds), "hit_cap" (per-query
  *            candidate capacity; overflow falls back to the exact scan);
  *            "profile" = N keeps N (start, stop) HIP-event pairs, one per heavy-kernel launch,

@@ -17,12 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 VARIANTS = {
-    "qs2": {"CODD_QS": 2},
-    "x_nohits": {"CODD_QS": 2, "CODD_EXP_NO_HITS": 1},
-    "x_sametile_nohits": {"CODD_QS": 2, "CODD_EXP_SAME_TILE": 1, "CODD_EXP_NO_HITS": 1},
-    "x_nb4_nohits": {"CODD_QS": 2, "CODD_EXP_NB": 4, "CODD_EXP_NO_HITS": 1},
-    "x_nb2_nohits": {"CODD_QS": 2, "CODD_EXP_NB": 2, "CODD_EXP_NO_HITS": 1},
-    "x_sametile_nb4_nohits": {"CODD_QS": 2, "CODD_EXP_SAME_TILE": 1, "CODD_EXP_NB": 4, "CODD_EXP_NO_HITS": 1},
+    "base": {},
+    "ring4": {"CODD_RING": 4},
+    "ring4_qs1": {"CODD_RING": 4, "CODD_QS": 1},
+    "ring2": {"CODD_RING": 2},
 }
 
 

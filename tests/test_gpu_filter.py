@@ -27,6 +27,7 @@ def build(Index, raw, dtype="f32", force_filter=True):
     ix.upsert(np.arange(raw.shape[0], dtype=np.int64), raw)
     if force_filter:
         ix.set_option("filter_min_rows", 1)
+        ix.set_option("filter_min_rows_small", 1)
         ix.set_option("filter_min_batch", 1)
     return ix
 
@@ -81,6 +82,34 @@ def test_filter_path_is_exact(Index, n, d, B, k, dtype):
     assert np.array_equal(dist, d_ref)
     assert ix.stat("fallback_queries") == 0, "random data must not need the fallback"
     assert ix.stat("filter_survivors") < ix.stat("filter_hits") <= B * 8192
+    ix.close()
+
+
+@pytest.mark.parametrize("B", [1, 5, 32, 33, 64, 100, 128, 129])
+def test_every_query_block_count_is_exact(Index, B):
+    """The GEMM is instantiated for 1, 2, 4 and 8 blocks of 32 queries; batch sizes on both sides of
+    every boundary must give the oracle's bits (B = 1 is the single-query latency path on large corpora)."""
+    rng = np.random.default_rng(100 + B)
+    n, d, k = 30_000, 768, 10
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((B, d)).astype(np.float32)
+    ix = build(Index, raw)
+    dist, rows = ix.search(q, k)
+    assert ix.stat("filter_passes") == 1 and ix.stat("fallback_queries") == 0
+    d_ref, i_ref = oracle_answer(raw, q, k, "f32")
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    ix.close()
+
+
+def test_small_batches_take_the_exact_scan_on_small_corpora(Index):
+    rng = np.random.default_rng(4)
+    raw = rng.standard_normal((40_000, 128)).astype(np.float32)
+    ix = Index(128)
+    ix.upsert(np.arange(40_000, dtype=np.int64), raw)
+    ix.search(rng.standard_normal((4, 128)).astype(np.float32), 5)      # B < 16, rows < 500k: scan
+    assert ix.stat("filter_passes") == 0
+    ix.search(rng.standard_normal((16, 128)).astype(np.float32), 5)     # B >= 16, rows >= 32768: filter
+    assert ix.stat("filter_passes") == 1
     ix.close()
 
 
