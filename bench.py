@@ -46,6 +46,8 @@ def parse_args():
     p.add_argument("--cpu-sample-queries", type=int, default=256)
     p.add_argument("--cpu-seconds", type=float, default=10.0)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--force-dist", action="store_true",
+                   help="initialise RCCL and take the sharded code path even with one rank (rehearsal on a 1-GPU box)")
     return p.parse_args()
 
 
@@ -128,6 +130,10 @@ def measured_traffic(kernel, dtype, dim, n_local):
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE JSON line: library banners (RCCL prints its version to stdout) go to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
 
@@ -141,11 +147,13 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from codd_query_engine_amd.knn_index import DeviceKnnIndex
     from codd_query_engine_amd.sharded import ShardedSearcher, shard_bounds
@@ -159,7 +167,7 @@ def main():
     ix = DeviceKnnIndex(d, args.dtype, str(device))
     build_shard(ix, torch, lo, hi, N, d, queries, n_planted_q, k, device)
     t_build = time.perf_counter() - t_build
-    searcher = ShardedSearcher(ix, row_base=lo) if world > 1 else None
+    searcher = ShardedSearcher(ix, row_base=lo, always_gather=args.force_dist) if use_dist else None
 
     def step(q):
         if searcher is not None:
@@ -167,7 +175,7 @@ def main():
         return ix.search_tensors(q, k)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -197,7 +205,7 @@ def main():
     ix.set_option("profile", 0)
     filter_stats = {key: ix.stat(key) for key in ("filter_passes", "fallback_queries", "filter_hits", "filter_survivors")}
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -270,10 +278,11 @@ def main():
             line["cpu_baseline"] = cpu_baseline(ix, args, queries.cpu().numpy())
         except Exception as e:  # the baseline must never take the GPU number down with it
             line["cpu_baseline"] = {"value": None, "unit": "queries/s", "cores": None, "kind": "port", "sample": f"failed: {e}"}
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     ix.close()
-    if world > 1:
+    if use_dist:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
     if not valid:

@@ -100,6 +100,32 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
     }
 }
 
+// shadow_from_rows_kernel: rebuild the bf16 fragment-order shadow of rows [first, first+n) from the
+// stored rows themselves (index load from disk: the rows arrive already normalised and rounded).
+template <int DT>
+__global__ __launch_bounds__(256) void shadow_from_rows_kernel(const void* __restrict__ rows_, int64_t first, int64_t n, int dpad,
+                                                               uint2* __restrict__ shadow) {
+    const int lane = lane_id();
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int64_t row = first + r;
+    const int nch = dpad >> 2, nsteps = dpad >> 6;
+    for (int j = lane; j < nch; j += kWave) {
+        float v[4];
+        if (DT == DT_F32) {
+            const float4 x = reinterpret_cast<const float4*>(rows_)[row * (int64_t)nch + j];
+            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+        } else {
+            const uint2 x = reinterpret_cast<const uint2*>(rows_)[row * (int64_t)nch + j];
+            const uint16_t hb[4] = {(uint16_t)(x.x & 0xffffu), (uint16_t)(x.x >> 16), (uint16_t)(x.y & 0xffffu), (uint16_t)(x.y >> 16)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = DT == DT_BF16 ? __uint_as_float((uint32_t)hb[e] << 16) : f16_bits_to_f32(hb[e]);
+        }
+        const int64_t piece = shadow_piece_index(row, j >> 1, nsteps);
+        shadow[piece * 2 + (j & 1)] = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // scan_topk_kernel<DT, NB, NITER, SLOTS>: exact canonical-score scan of the whole row store for
 // up to NB queries at once.
@@ -301,7 +327,8 @@ struct codd_knn_index {
     int64_t filter_min_rows = 32768;
     int64_t filter_min_rows_small = 500000;  // batches below filter_min_batch
     int filter_min_batch = 16;
-    int sample_tiles = 1024;
+    int sample_tiles = 1024;  // upper bound on sampled tiles
+    int sample_div = 40;      // sample about 1/40 of the tiles (2.5 % extra GEMM work), see sample_tile_count()
     int hit_cap_q = 8192;
 
     // workspaces (grown on demand, never inside a captured region after warm-up)
@@ -613,6 +640,18 @@ int ensure_filter_workspace(codd_knn_index* ix) {
     return CODD_KNN_OK;
 }
 
+// how many evenly spaced tiles set the thresholds: ~ntiles/sample_div (so the sample costs a fixed
+// fraction of the main pass at every shard size and the hit volume per query stays ~k*sample_div),
+// at least max(64, 4k) where the corpus has that many tiles, at most sample_tiles
+int64_t sample_tile_count(const codd_knn_index* ix, int64_t ntiles, int k) {
+    int64_t ts = ntiles / ix->sample_div;
+    const int64_t lo = 4 * (int64_t)k > 64 ? 4 * (int64_t)k : 64;
+    if (ts < lo) ts = lo;
+    if (ts > ix->sample_tiles) ts = ix->sample_tiles;
+    if (ts > ntiles) ts = ntiles;
+    return ts < 1 ? 1 : ts;
+}
+
 // one pass of <= 256 queries through sample -> threshold -> filter -> finalize (+ exact fallback)
 int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row_base, u64* keys_out, hipStream_t st) {
     const int64_t n = ix->count;
@@ -627,8 +666,8 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(ix->ctl, 0, sizeof(FilterCtl), st));
 
-    // sample: every `stride`-th tile, at most sample_tiles of them
-    const int64_t ts = ntiles < ix->sample_tiles ? ntiles : ix->sample_tiles;
+    // sample: every `stride`-th tile
+    const int64_t ts = sample_tile_count(ix, ntiles, k);
     const int64_t stride = ntiles / ts;
     const int nbq = nq <= 32 ? 1 : (nq <= 64 ? 2 : (nq <= 128 ? 4 : 8));  // 32-query blocks the GEMM multiplies
     {
@@ -702,7 +741,7 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
 bool filter_applies(const codd_knn_index* ix, int B, int k) {
     // the thresholds come from the k-th largest of the sampled tile maxima: need comfortably more tiles than k
     const int64_t ntiles = (ix->count + kTileRows - 1) / kTileRows;
-    const int64_t ts = ntiles < ix->sample_tiles ? ntiles : ix->sample_tiles;
+    const int64_t ts = sample_tile_count(ix, ntiles, k);
     if (!(ix->filter_enabled && ix->all_normalized && ix->shadow) || ts < 2 * (int64_t)k) return false;
     // large batches: always worth it past a few tiles per CU; small batches (the single-query latency
     // point): the bf16 stream halves the bytes, which beats the extra launches from ~0.5M rows on
@@ -858,6 +897,29 @@ int codd_knn_upsert_device(codd_knn_index* ix, int64_t first_slot, const float* 
     return CODD_KNN_OK;
 }
 
+int codd_knn_load_rows(codd_knn_index* ix, int64_t first_slot, const void* host_rows, int64_t n) {
+    if (!ix || first_slot < 0 || n < 0 || (n > 0 && !host_rows)) return fail(CODD_KNN_EINVAL, "bad load_rows arguments%s");
+    if (n == 0) return CODD_KNN_OK;
+    if (first_slot + n >= 0xffffffffll) return fail(CODD_KNN_EINVAL, "row slots must fit 32 bits%s");
+    DeviceGuard guard(ix->device);
+    HIP_TRY(hipDeviceSynchronize());
+    int rc = grow_rows(ix, first_slot + n, /*exact=*/false);
+    if (rc != 0) return rc;
+    const size_t row_bytes = (size_t)ix->dpad * elem_size(ix->dtype);
+    HIP_TRY(hipMemcpy((char*)ix->rows + (size_t)first_slot * row_bytes, host_rows, (size_t)n * row_bytes, hipMemcpyHostToDevice));
+    const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+    uint2* sh = reinterpret_cast<uint2*>(ix->shadow);
+    switch (ix->dtype) {
+        case DT_F32: hipLaunchKernelGGL(shadow_from_rows_kernel<DT_F32>, grid, block, 0, nullptr, ix->rows, first_slot, n, ix->dpad, sh); break;
+        case DT_BF16: hipLaunchKernelGGL(shadow_from_rows_kernel<DT_BF16>, grid, block, 0, nullptr, ix->rows, first_slot, n, ix->dpad, sh); break;
+        default: hipLaunchKernelGGL(shadow_from_rows_kernel<DT_F16>, grid, block, 0, nullptr, ix->rows, first_slot, n, ix->dpad, sh); break;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    if (first_slot + n > ix->count) ix->count = first_slot + n;
+    return CODD_KNN_OK;
+}
+
 int codd_knn_count(const codd_knn_index* ix, int64_t* out) {
     if (!ix || !out) return fail(CODD_KNN_EINVAL, "bad count arguments%s");
     *out = ix->count;
@@ -932,6 +994,11 @@ int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {
     if (strcmp(key, "sample_tiles") == 0) {
         if (value < 1 || value > 65536) return fail(CODD_KNN_EINVAL, "sample_tiles must be in [1,65536]%s");
         ix->sample_tiles = (int)value;
+        return CODD_KNN_OK;
+    }
+    if (strcmp(key, "sample_div") == 0) {
+        if (value < 1 || value > 4096) return fail(CODD_KNN_EINVAL, "sample_div must be in [1,4096]%s");
+        ix->sample_div = (int)value;
         return CODD_KNN_OK;
     }
     if (strcmp(key, "hit_cap") == 0) {

@@ -12,10 +12,25 @@ default engine factory raises if the library or the GPU is missing.
 
 `engine_factory(dim) -> engine` exists so that host-logic tests can stand the façade on a
 checker engine of their own (tests/_oracle_engine.py); products never pass it.
+
+Persistence (`KnnClient(path=...)`, the role of `SemanticStoreConfig.chromadb_path`, declared and
+never read in the reference, codd_lib/codd_lib/config/semantic_store_config.py:13): the indexer job
+and the service are different processes that share state only through the Chroma server; here they
+share a directory.  Layout per collection:
+
+    <path>/<collection>/CURRENT            name of the live generation (replaced atomically, last)
+    <path>/<collection>/gen-<n>/manifest.json   name, metadata, dim, padded_dim, dtype, count
+                               /rows.bin        stored rows exactly as they sit in HBM
+                               /ids.json, metadatas.jsonl, documents.jsonl
+
+`persist()` writes a new generation and flips CURRENT; `reload()` picks up a newer generation.
 """
 
 from __future__ import annotations
 
+import json
+import os
+import shutil
 import time
 from typing import Any, Callable, Optional, Sequence
 
@@ -24,6 +39,7 @@ import numpy as np
 from .embedding import EmbeddingFunction, HashingEmbeddingFunction
 
 _SUPPORTED_SPACES = ("cosine",)
+FORMAT_VERSION = 1  # of the on-disk layout
 
 
 def _default_engine_factory(device: str, dtype: str) -> Callable[[int], Any]:
@@ -53,6 +69,8 @@ class Collection:
         self._slot_of: dict[str, int] = {}
         self._documents: list[Optional[str]] = []
         self._metadatas: list[Optional[dict]] = []
+        self._dirty = False
+        self._generation = 0
 
     # ------------------------------------------------------------------ helpers
     def _engine_for(self, dim: int):
@@ -120,6 +138,7 @@ class Collection:
                 self._documents[slot] = documents[i]
             if metadatas is not None:
                 self._metadatas[slot] = dict(metadatas[i]) if metadatas[i] is not None else None
+        self._dirty = True
 
     def add(self, ids: Sequence[str], embeddings=None, metadatas=None, documents=None) -> None:
         """chromadb Collection.add: like upsert, but ids already present are left untouched."""
@@ -182,6 +201,83 @@ class Collection:
         return out
 
 
+    # ------------------------------------------------------------------ persistence
+    def _write_generation(self, directory: str) -> None:
+        """Write gen-<n+1> under `directory`, then flip CURRENT (atomic rename)."""
+        gen = self._generation + 1
+        name = f"gen-{gen:08d}"
+        tmp = os.path.join(directory, f".{name}.tmp-{os.getpid()}")
+        shutil.rmtree(tmp, ignore_errors=True)
+        os.makedirs(tmp)
+        n = len(self._ids)
+        manifest = {"format_version": FORMAT_VERSION, "name": self.name, "metadata": self.metadata, "count": n,
+                    "dim": None, "padded_dim": None, "dtype": None}
+        if self._engine is not None and n:
+            rows = self._engine.read_rows(0, n)
+            manifest.update(dim=self._engine.dim, padded_dim=int(rows.shape[1]), dtype=getattr(self._engine, "dtype", "f32"))
+            rows.tofile(os.path.join(tmp, "rows.bin"))
+        with open(os.path.join(tmp, "ids.json"), "w") as f:
+            json.dump(self._ids, f, ensure_ascii=False)
+        for fname, seq in (("metadatas.jsonl", self._metadatas), ("documents.jsonl", self._documents)):
+            with open(os.path.join(tmp, fname), "w") as f:
+                for item in seq:
+                    f.write(json.dumps(item, ensure_ascii=False) + "\n")
+        with open(os.path.join(tmp, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=1, ensure_ascii=False)
+        final = os.path.join(directory, name)
+        shutil.rmtree(final, ignore_errors=True)
+        os.replace(tmp, final)
+        cur_tmp = os.path.join(directory, f".CURRENT.tmp-{os.getpid()}")
+        with open(cur_tmp, "w") as f:
+            f.write(name)
+        os.replace(cur_tmp, os.path.join(directory, "CURRENT"))
+        for old in os.listdir(directory):  # keep the previous generation for a reader that is mid-load
+            if old.startswith("gen-") and old not in (name, f"gen-{gen - 1:08d}"):
+                shutil.rmtree(os.path.join(directory, old), ignore_errors=True)
+        self._generation = gen
+        self._dirty = False
+
+    @staticmethod
+    def _current_generation(directory: str) -> Optional[str]:
+        try:
+            with open(os.path.join(directory, "CURRENT")) as f:
+                return f.read().strip() or None
+        except OSError:
+            return None
+
+    def _load_generation(self, directory: str, gen_name: str) -> None:
+        gdir = os.path.join(directory, gen_name)
+        with open(os.path.join(gdir, "manifest.json")) as f:
+            manifest = json.load(f)
+        if manifest.get("format_version") != FORMAT_VERSION:
+            raise ValueError(f"{gdir}: unsupported index format {manifest.get('format_version')}")
+        with open(os.path.join(gdir, "ids.json")) as f:
+            ids = json.load(f)
+        read_lines = lambda fname: [json.loads(line) for line in open(os.path.join(gdir, fname))]  # noqa: E731
+        metadatas, documents = read_lines("metadatas.jsonl"), read_lines("documents.jsonl")
+        n = manifest["count"]
+        if not (len(ids) == len(metadatas) == len(documents) == n):
+            raise ValueError(f"{gdir}: sidecar lengths disagree with the manifest")
+        engine = None
+        if n and manifest["dim"]:
+            dtype = manifest["dtype"]
+            rows = np.fromfile(os.path.join(gdir, "rows.bin"), dtype=np.float32 if dtype == "f32" else np.uint16)
+            rows = rows.reshape(n, manifest["padded_dim"])
+            engine = self._engine_factory(manifest["dim"])
+            if getattr(engine, "dtype", dtype) != dtype:
+                raise ValueError(f"{gdir}: stored dtype {dtype} does not match the client's dtype {engine.dtype}")
+            engine.load_rows(rows, 0)
+        old = self._engine
+        self._engine = engine
+        if old is not None and hasattr(old, "close"):
+            old.close()
+        self.metadata = dict(manifest.get("metadata") or {})
+        self._ids, self._metadatas, self._documents = ids, metadatas, documents
+        self._slot_of = {doc_id: i for i, doc_id in enumerate(ids)}
+        self._generation = int(gen_name.split("-")[1])
+        self._dirty = False
+
+
 class KnnClient:
     """Stands where `chromadb.HttpClient(host, port)` / `EphemeralClient()` stand.
 
@@ -193,12 +289,60 @@ class KnnClient:
     """
 
     def __init__(self, device: str = "cuda:0", dtype: str = "f32", embedding_function: Optional[EmbeddingFunction] = None,
-                 engine_factory: Optional[Callable[[int], Any]] = None):
+                 engine_factory: Optional[Callable[[int], Any]] = None, path: Optional[str] = None):
         self.device = device
         self.dtype = dtype
+        self.path = path
         self._embed = embedding_function or HashingEmbeddingFunction()
         self._engine_factory = engine_factory or _default_engine_factory(device, dtype)
         self._collections: dict[str, Collection] = {}
+        if path is not None:
+            os.makedirs(path, exist_ok=True)
+            for entry in sorted(os.listdir(path)):
+                cdir = os.path.join(path, entry)
+                gen = Collection._current_generation(cdir) if os.path.isdir(cdir) else None
+                if gen:
+                    col = Collection(entry, None, self._embed, self._engine_factory)
+                    col._load_generation(cdir, gen)
+                    self._collections[col.name] = col
+
+    # ------------------------------------------------------------------ persistence
+    def _dir_of(self, name: str) -> str:
+        if os.sep in name or name.startswith("."):
+            raise ValueError(f"collection name {name!r} cannot be used as a directory name")
+        return os.path.join(self.path, name)
+
+    def persist(self) -> int:
+        """Write every changed collection to `path` (new generation + CURRENT flip). Returns how many."""
+        if self.path is None:
+            return 0
+        written = 0
+        for col in self._collections.values():
+            if col._dirty or col._generation == 0:
+                cdir = self._dir_of(col.name)
+                os.makedirs(cdir, exist_ok=True)
+                col._write_generation(cdir)
+                written += 1
+        return written
+
+    def reload(self) -> int:
+        """Pick up generations another process (the indexer job) has published since we loaded."""
+        if self.path is None:
+            return 0
+        loaded = 0
+        for entry in sorted(os.listdir(self.path)):
+            cdir = os.path.join(self.path, entry)
+            gen = Collection._current_generation(cdir) if os.path.isdir(cdir) else None
+            if not gen:
+                continue
+            col = self._collections.get(entry)
+            if col is None:
+                col = Collection(entry, None, self._embed, self._engine_factory)
+                self._collections[entry] = col
+            if int(gen.split("-")[1]) > col._generation:
+                col._load_generation(cdir, gen)
+                loaded += 1
+        return loaded
 
     def heartbeat(self) -> int:
         """Liveness probe (indexer_main.py:215,330): nanoseconds since the epoch, like chromadb."""
@@ -239,3 +383,5 @@ class KnnClient:
         eng = col._engine
         if eng is not None and hasattr(eng, "close"):
             eng.close()
+        if self.path is not None:
+            shutil.rmtree(self._dir_of(name), ignore_errors=True)

@@ -109,6 +109,14 @@ class DeviceKnnIndex:
         native.check(self._lib.codd_knn_read_rows(self._h, int(first), int(n), out.ctypes.data), "codd_knn_read_rows")
         return out
 
+    def load_rows(self, rows: np.ndarray, first_slot: int = 0) -> None:
+        """Stored rows as read_rows() returned them (persisted index) into slots [first_slot, ...)."""
+        want = np.float32 if self.dtype == "f32" else np.uint16
+        rows = np.ascontiguousarray(rows, dtype=want)
+        if rows.ndim != 2 or rows.shape[1] != self.padded_dim:
+            raise ValueError(f"expected stored rows [n,{self.padded_dim}], got {rows.shape}")
+        native.check(self._lib.codd_knn_load_rows(self._h, int(first_slot), rows.ctypes.data, rows.shape[0]), "codd_knn_load_rows")
+
     # ------------------------------------------------------------------ search
     def _queries_tensor(self, queries):
         torch = _torch()

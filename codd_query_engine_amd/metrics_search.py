@@ -24,7 +24,7 @@ def get_semantic_store(config: Optional[SemanticStoreConfig] = None, client: Any
     if client is None:
         from .embedding import HashingEmbeddingFunction
 
-        client = KnnClient(device=config.device, dtype=config.dtype,
+        client = KnnClient(device=config.device, dtype=config.dtype, path=config.chromadb_path,
                            embedding_function=HashingEmbeddingFunction(config.embedding_dim))
     return MetricsSemanticMetadataStore(client, collection_name=config.collection_name)
 

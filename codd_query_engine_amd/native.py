@@ -32,6 +32,7 @@ ABI = [
     ("codd_knn_reserve", ctypes.c_int, [_c_idx, ctypes.c_int64]),
     ("codd_knn_upsert_host", ctypes.c_int, [_c_idx, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]),
     ("codd_knn_upsert_device", ctypes.c_int, [_c_idx, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    ("codd_knn_load_rows", ctypes.c_int, [_c_idx, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]),
     ("codd_knn_count", ctypes.c_int, [_c_idx, _i64p]),
     ("codd_knn_dim", ctypes.c_int, [_c_idx, _intp, _intp, _intp]),
     ("codd_knn_read_rows", ctypes.c_int, [_c_idx, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),

@@ -40,10 +40,11 @@ class ShardedSearcher:
     """
 
     def __init__(self, engine: Any, row_base: int, group: Optional[Any] = None,
-                 merge: Optional[Callable[[Any, int], tuple]] = None):
+                 merge: Optional[Callable[[Any, int], tuple]] = None, always_gather: bool = False):
         import torch.distributed as dist
 
         self.engine = engine
+        self.always_gather = always_gather  # exercise the collective even with one rank (rehearsals)
         self.row_base = int(row_base)
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -63,7 +64,7 @@ class ShardedSearcher:
         import torch.distributed as dist
 
         local = self.search_keys_local(queries, k)  # [B,k] int64
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.always_gather:
             _, d, r = self._merge(local, k)
             return d, r
         B = local.shape[0]

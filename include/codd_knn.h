@@ -81,6 +81,14 @@ int codd_knn_upsert_host(codd_knn_index* index, const int64_t* host_slots, const
 int codd_knn_upsert_device(codd_knn_index* index, int64_t first_slot, const float* dev_vecs,
                            int64_t n, int normalize, void* stream);
 
+/*
+ * Counterpart of codd_knn_read_rows for loading a persisted index (the role of the Chroma
+ * server's docker volume, docker-compose.yml:8-9): `host_rows` are n stored rows exactly as
+ * codd_knn_read_rows returned them (storage dtype, padded width, already normalised); they are
+ * copied into slots [first_slot, first_slot+n) and the bf16 shadow is rebuilt.  Synchronous.
+ */
+int codd_knn_load_rows(codd_knn_index* index, int64_t first_slot, const void* host_rows, int64_t n);
+
 /* Number of row slots in use (highest written slot + 1) — collection.count(). */
 int codd_knn_count(const codd_knn_index* index, int64_t* out);
 int codd_knn_dim(const codd_knn_index* index, int* dim, int* padded_dim, int* dtype);
@@ -126,7 +134,8 @@ int codd_knn_debug_filter_scores(codd_knn_index* index, const float* dev_queries
  *   options: "scan_blocks_per_cu" (1..8); "filter" (0/1: MFMA filter path for large batches);
  *            "filter_min_batch" (16), "filter_min_rows" (32768, batches >= filter_min_batch),
  *            "filter_min_rows_small" (500000, smaller batches): when the filter path is taken;
- *            "sample_tiles" (tiles that set the per-query thresholds), "hit_cap" (per-query
+ *            "sample_div" (40: about 1/40 of the tiles set the per-query thresholds), "sample_tiles"
+ *            (1024: upper bound on that number), "hit_cap" (per-query
  *            candidate capacity; overflow falls back to the exact scan);
  *            "profile" = N keeps N (start, stop) HIP-event pairs, one per heavy-kernel launch,
  *            recorded on the launch stream (0 = off; resets the log)

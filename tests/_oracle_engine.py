@@ -40,6 +40,16 @@ class OracleEngine:
         n = self.count() - first if n is None else n
         return self._rows[first : first + n].copy()
 
+    def load_rows(self, rows, first_slot: int = 0) -> None:
+        rows = np.ascontiguousarray(rows, dtype=self._rows.dtype)
+        assert rows.shape[1] == self.padded_dim
+        need = first_slot + rows.shape[0]
+        if need > self._rows.shape[0]:
+            grown = np.zeros((need, self.padded_dim), dtype=self._rows.dtype)
+            grown[: self._rows.shape[0]] = self._rows
+            self._rows = grown
+        self._rows[first_slot:need] = rows
+
     def _prep(self, queries) -> np.ndarray:
         q = np.ascontiguousarray(queries, dtype=np.float32)
         assert q.ndim == 2 and q.shape[1] == self.dim
