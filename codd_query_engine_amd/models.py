@@ -8,7 +8,9 @@ Counterparts (field for field) of the reference's
 
 from __future__ import annotations
 
-from typing import Optional, TypedDict
+from typing import Optional
+
+from typing_extensions import TypedDict  # pydantic needs this flavour below Python 3.12
 
 from pydantic import BaseModel
 
