@@ -323,9 +323,9 @@ __global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_
                                         lds_hits[slot * 3 + 2] = (unsigned)(nb * 32 + c);
                                     } else {
                                         // list full (> kHitCap/2 hits inside ONE tile): this query's candidates
-                                        // are incomplete -> push its counter past the cap so that finalize
-                                        // sends exactly this query to the exact-scan fallback
-                                        atomicAdd(&hit_cnt[nb * 32 + c], (unsigned)cap_q + 1u);
+                                        // are incomplete -> poison its counter (top bit: reads as "> cap" and can
+                                        // never wrap) so that finalize sends exactly this query to the exact scan
+                                        atomicOr(&hit_cnt[nb * 32 + c], 0x80000000u);
                                     }
                                 }
                             }

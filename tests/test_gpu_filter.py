@@ -135,6 +135,25 @@ def test_overflow_falls_back_and_stays_exact(Index):
     ix.close()
 
 
+def test_workgroup_hit_list_overflow_poisons_only_the_affected_queries(Index):
+    """One tile holds 256 near-copies of a vector and 24 queries point at it: 6,144 hits land in one
+    workgroup's 2,048-entry LDS list inside a single tile.  The affected queries must go to the exact
+    scan (top-bit poison on their counters), the others must not, and every answer stays exact."""
+    rng = np.random.default_rng(6)
+    n, d, B, k = 36_000, 256, 40, 10
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    centre = rng.standard_normal(d).astype(np.float32)
+    raw[5120:5376] = centre + 1e-3 * rng.standard_normal((256, d)).astype(np.float32)  # exactly tile 20
+    q = rng.standard_normal((B, d)).astype(np.float32)
+    q[:24] = centre + 1e-3 * rng.standard_normal((24, d)).astype(np.float32)
+    ix = build(Index, raw)
+    dist, rows = ix.search(q, k)
+    d_ref, i_ref = oracle_answer(raw, q, k, "f32")
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    assert 1 <= ix.stat("fallback_queries") <= 24
+    ix.close()
+
+
 def test_ties_resolve_to_lower_row_through_the_filter(Index):
     rng = np.random.default_rng(2)
     n, d = 35_000, 768
