@@ -56,6 +56,9 @@ constexpr int kQP = kStagePieces / kFilterThreads;  // query-slice pieces each t
 #ifndef CODD_STATIC_PRIO
 #define CODD_STATIC_PRIO 0   // waves 4..7 (the second wave of every SIMD) run at s_setprio 1 for the whole kernel
 #endif
+#ifndef CODD_NT_LOADS
+#define CODD_NT_LOADS 1      // corpus fragments with the non-temporal cache policy (read-once stream)
+#endif
 #ifndef CODD_NO_EPILOGUE
 #define CODD_NO_EPILOGUE 0   // diagnostic only: skip the threshold test (results are wrong)
 #endif
@@ -191,7 +194,15 @@ __global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_
             const int64_t block = (CODD_EXP_SAME_TILE ? 0 : l_u * tile_stride * 8) + wave * kRB + rb;
             const uint4* p = shadow + ((block * nsteps + l_s) * 4) * 64 + lane;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) dst[rb][kk] = p[kk * 64];
+            for (int kk = 0; kk < 4; ++kk) {
+#if CODD_NT_LOADS
+                typedef unsigned v4u __attribute__((ext_vector_type(4)));
+                const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p + kk * 64));
+                dst[rb][kk] = make_uint4(t.x, t.y, t.z, t.w);
+#else
+                dst[rb][kk] = p[kk * 64];
+#endif
+            }
         }
         if (--l_left > 0) {
             if (++l_s == nsteps) { l_s = 0; l_u += G; }

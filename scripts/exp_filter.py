@@ -18,9 +18,8 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "base": {},
-    "ring4": {"CODD_RING": 4},
-    "ring4_qs1": {"CODD_RING": 4, "CODD_QS": 1},
-    "ring2": {"CODD_RING": 2},
+    "nt": {"CODD_NT_LOADS": 1},
+    "nt_ring2": {"CODD_NT_LOADS": 1, "CODD_RING": 2},
 }
 
 
