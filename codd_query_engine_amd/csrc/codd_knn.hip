@@ -273,6 +273,123 @@ __global__ __launch_bounds__(256) void merge_keys_kernel(const u64* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// IVF (coarse lists + exact scores), SURVEY.md §8(f)4 / BASELINE config 5.
+// gather_rows_kernel: rows_ivf[i] = rows[perm[i]] (rows regrouped by coarse list), one wave per row.
+// widen_rows_kernel : stored rows -> fp32 [n][dim] (index build reads the corpus back through it).
+// ivf_scan_kernel   : block (x, b) scans slice x%split of the list that query b probes at rank x/split,
+//                     canonical exact scores, per-wave top-k, keys carry the ORIGINAL row slot.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restrict__ src, const int64_t* __restrict__ perm, int64_t n,
+                                                          int chunks_per_row, uint4* __restrict__ dst, uint32_t* __restrict__ ids) {
+    const int lane = lane_id();
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int64_t from = perm[r];
+    for (int j = lane; j < chunks_per_row; j += kWave) dst[r * chunks_per_row + j] = src[from * chunks_per_row + j];
+    if (lane == 0) ids[r] = (uint32_t)from;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void widen_rows_kernel(const void* __restrict__ rows_, int64_t first, int64_t n, int dim, int dpad,
+                                                         float* __restrict__ out) {
+    typedef RowTraits<DT> RT;
+    constexpr int E = RT::E;
+    const int lane = lane_id();
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int nchunks = dpad / E;
+    const uint4* p = reinterpret_cast<const uint4*>(rows_) + (first + r) * (int64_t)nchunks;
+    for (int j = lane; j < nchunks; j += kWave) {
+        float w[E];
+        RT::widen(p[j], w);
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (j * E + e < dim) out[r * (int64_t)dim + j * E + e] = w[e];
+    }
+}
+
+template <int DT, int NITER, int SLOTS>
+__global__ __launch_bounds__(256) void ivf_scan_kernel(const void* __restrict__ rows_, const uint32_t* __restrict__ ids,
+                                                       const int64_t* __restrict__ offsets, const u64* __restrict__ probe_keys,
+                                                       int nprobe, int split, int dpad, const float* __restrict__ qn, int k,
+                                                       uint32_t row_base, u64* __restrict__ partial) {
+    typedef RowTraits<DT> RT;
+    constexpr int E = RT::E;
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    const int b = blockIdx.y, x = blockIdx.x;
+    const int nchunks = dpad / E;
+    u64* dst = partial + ((int64_t)b * nprobe * split + x) * k;
+
+    WaveTopK<SLOTS> L;
+    L.init();
+    const u64 pk = probe_keys[(int64_t)b * nprobe + x / split];
+    if (pk != 0ull) {  // block-uniform: fewer lists than nprobe leave empty probe slots
+        const uint32_t list = key_row(pk);
+        const int64_t lo = offsets[list], hi = offsets[list + 1];
+        const int64_t len = hi - lo, part = (len + split - 1) / split;
+        const int64_t begin = lo + (x % split) * part;
+        const int64_t end = begin + part < hi ? begin + part : hi;
+
+        float qf[NITER][E];
+#pragma unroll
+        for (int it = 0; it < NITER; ++it) {
+            const int j = lane + kWave * it;
+#pragma unroll
+            for (int e = 0; e < E; ++e) qf[it][e] = j < nchunks ? qn[(int64_t)b * dpad + (int64_t)j * E + e] : 0.0f;
+        }
+        const uint4* base = reinterpret_cast<const uint4*>(rows_);
+        for (int64_t g = begin + wave * 4; g < end; g += 16) {
+            float w[4][NITER][E];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = g + r < end ? g + r : end - 1;
+                const uint4* p = base + row * (int64_t)nchunks + lane;
+#pragma unroll
+                for (int it = 0; it < NITER; ++it) {
+                    uint4 c = make_uint4(0u, 0u, 0u, 0u);
+                    if (lane + kWave * it < nchunks) c = p[kWave * it];
+                    RT::widen(c, w[r][it]);
+                }
+            }
+            float a[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int it = 0; it < NITER; ++it)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc = __builtin_fmaf(qf[it][e], w[r][it][e], acc);
+                a[r] = acc;
+            }
+            const float y = butterfly_sum4(a[0], a[1], a[2], a[3], lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(y), 16 * r));
+                if (g + r < end) L.offer(make_key(s, row_base + ids[g + r]), k, lane);
+            }
+        }
+    }
+    __shared__ u64 lds[4 * SLOTS * kWave];
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) lds[(wave * SLOTS + s) * kWave + lane] = L.v[s];
+    __syncthreads();
+    if (wave != 0) return;
+    for (int wv = 1; wv < 4; ++wv)
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            u64 cand = lds[(wv * SLOTS + s) * kWave + lane];
+            if (s * kWave + lane >= k) cand = 0ull;
+            L.offer_lanes(cand, k, lane);
+        }
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int rank = s * kWave + lane;
+        if (rank < k) dst[rank] = L.v[s];
+    }
+}
+
 // gathers the fallback queries' normalised vectors into a dense block: dst[i] = qn[list[i]]
 __global__ __launch_bounds__(256) void gather_queries_kernel(const float* __restrict__ qn, const unsigned* __restrict__ list,
                                                              int count, int dpad, float* __restrict__ dst) {
@@ -343,6 +460,17 @@ struct codd_knn_index {
     FilterCtl* ctl_host = nullptr;                         // pinned host mirror
     float* qn_fb = nullptr;    int64_t qn_fb_cap = 0;     // gathered fallback queries
     u64* keys_fb = nullptr;    int64_t keys_fb_cap = 0;
+
+    // IVF (optional): rows regrouped by coarse list, original slots, list offsets, the coarse index
+    codd_knn_index* coarse = nullptr;  // nlist centroids, f32
+    void* rows_ivf = nullptr;
+    uint32_t* ivf_ids = nullptr;
+    int64_t* ivf_offsets = nullptr;    // [nlist + 1]
+    int64_t ivf_count = 0;             // rows covered by the IVF layout (must equal count to be fresh)
+    int ivf_nlist = 0;
+    int64_t ivf_epoch = -1, epoch = 0;  // epoch bumps on every row write; search requires ivf_epoch == epoch
+    u64* probe_keys = nullptr; int64_t probe_cap = 0;
+    u64* ivf_partial = nullptr; int64_t ivf_partial_cap = 0;
 
     int64_t stat_searches = 0, stat_scan_launches = 0, stat_last_scan_blocks = 0;
     int64_t stat_filter_passes = 0, stat_fallback_queries = 0, stat_hits = 0, stat_survivors = 0;
@@ -821,6 +949,10 @@ int codd_knn_destroy(codd_knn_index* ix) {
                     ix->hits, ix->ctl, ix->qn_fb, ix->keys_fb};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
+    void* ivf_bufs[] = {ix->rows_ivf, ix->ivf_ids, ix->ivf_offsets, ix->probe_keys, ix->ivf_partial};
+    for (void* b : ivf_bufs)
+        if (b) (void)hipFree(b);
+    if (ix->coarse) (void)codd_knn_destroy(ix->coarse);
     if (ix->ctl_host) (void)hipHostFree(ix->ctl_host);
     for (hipEvent_t e : ix->ev) (void)hipEventDestroy(e);
     delete ix;
@@ -874,6 +1006,7 @@ int codd_knn_upsert_host(codd_knn_index* ix, const int64_t* host_slots, const fl
     (void)hipFree(dslot);
     if (rc == 0) {
         if (max_slot + 1 > ix->count) ix->count = max_slot + 1;
+        ix->epoch++;
         if (!normalize) ix->all_normalized = false;
     }
     return rc;
@@ -893,6 +1026,7 @@ int codd_knn_upsert_device(codd_knn_index* ix, int64_t first_slot, const float* 
                               reinterpret_cast<uint2*>(ix->shadow), (hipStream_t)stream);
     if (rc != 0) return rc;
     if (first_slot + n > ix->count) ix->count = first_slot + n;
+    ix->epoch++;
     if (!normalize) ix->all_normalized = false;
     return CODD_KNN_OK;
 }
@@ -917,6 +1051,7 @@ int codd_knn_load_rows(codd_knn_index* ix, int64_t first_slot, const void* host_
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     if (first_slot + n > ix->count) ix->count = first_slot + n;
+    ix->epoch++;
     return CODD_KNN_OK;
 }
 
@@ -962,7 +1097,7 @@ int codd_knn_merge_keys(int device, const uint64_t* dev_keys_in, int B, int m, i
     return launch_merge((const u64*)dev_keys_in, B, m, m, k, (u64*)dev_keys_out, dev_dist, dev_rows, (hipStream_t)stream);
 }
 
-int codd_knn_debug_filter_scores(codd_knn_index* ix, const float* dev_queries, int B, float* dev_scores, void* stream) {
+int codd_knn_approx_scores(codd_knn_index* ix, const float* dev_queries, int B, float* dev_scores, void* stream) {
     if (!ix || !dev_queries || !dev_scores || B < 1 || B > kTileQ) return fail(CODD_KNN_EINVAL, "bad debug arguments%s");
     if (ix->count < 1 || !ix->shadow) return fail(CODD_KNN_EINVAL, "empty index%s");
     DeviceGuard guard(ix->device);
@@ -978,6 +1113,104 @@ int codd_knn_debug_filter_scores(codd_knn_index* ix, const float* dev_queries, i
                        ix->qfrag, ix->count, ix->dpad / 64, ntiles, (int64_t)1, nullptr, nullptr, nullptr, nullptr, 0, nullptr, dev_scores);
     HIP_TRY(hipGetLastError());
     return CODD_KNN_OK;
+}
+
+int codd_knn_copy_rows_f32(const codd_knn_index* ix, int64_t first, int64_t n, float* dev_out, void* stream) {
+    if (!ix || first < 0 || n < 0 || first + n > ix->count || (n > 0 && !dev_out)) return fail(CODD_KNN_EINVAL, "bad copy_rows range%s");
+    if (n == 0) return CODD_KNN_OK;
+    DeviceGuard guard(ix->device);
+    const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (ix->dtype) {
+        case DT_F32: hipLaunchKernelGGL(widen_rows_kernel<DT_F32>, grid, block, 0, st, ix->rows, first, n, ix->dim, ix->dpad, dev_out); break;
+        case DT_BF16: hipLaunchKernelGGL(widen_rows_kernel<DT_BF16>, grid, block, 0, st, ix->rows, first, n, ix->dim, ix->dpad, dev_out); break;
+        default: hipLaunchKernelGGL(widen_rows_kernel<DT_F16>, grid, block, 0, st, ix->rows, first, n, ix->dim, ix->dpad, dev_out); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return CODD_KNN_OK;
+}
+
+int codd_knn_ivf_install(codd_knn_index* ix, const float* dev_centroids, int nlist, const int64_t* dev_perm,
+                         const int64_t* dev_offsets, void* stream) {
+    if (!ix || !dev_centroids || !dev_perm || !dev_offsets || nlist < 1 || nlist > (1 << 20)) return fail(CODD_KNN_EINVAL, "bad ivf_install arguments%s");
+    if (ix->count < 1) return fail(CODD_KNN_EINVAL, "empty index%s");
+    DeviceGuard guard(ix->device);
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipDeviceSynchronize());
+    // drop a previous layout
+    void* old[] = {ix->rows_ivf, ix->ivf_ids, ix->ivf_offsets};
+    for (void* b : old)
+        if (b) (void)hipFree(b);
+    ix->rows_ivf = nullptr; ix->ivf_ids = nullptr; ix->ivf_offsets = nullptr;
+    if (ix->coarse) { (void)codd_knn_destroy(ix->coarse); ix->coarse = nullptr; }
+    ix->ivf_epoch = -1;
+
+    const size_t row_bytes = (size_t)ix->dpad * elem_size(ix->dtype);
+    const int64_t n = ix->count;
+    HIP_TRY(hipMalloc(&ix->rows_ivf, (size_t)n * row_bytes));
+    HIP_TRY(hipMalloc((void**)&ix->ivf_ids, (size_t)n * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&ix->ivf_offsets, (size_t)(nlist + 1) * sizeof(int64_t)));
+    HIP_TRY(hipMemcpyAsync(ix->ivf_offsets, dev_offsets, (size_t)(nlist + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, reinterpret_cast<const uint4*>(ix->rows), dev_perm, n,
+                       (int)(row_bytes / 16), reinterpret_cast<uint4*>(ix->rows_ivf), ix->ivf_ids);
+    HIP_TRY(hipGetLastError());
+    int rc = codd_knn_create(&ix->coarse, ix->device, ix->dim, DT_F32, CODD_KNN_METRIC_COSINE);
+    if (rc != 0) return rc;
+    if ((rc = codd_knn_upsert_device(ix->coarse, 0, dev_centroids, nlist, 1, stream)) != 0) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    ix->ivf_nlist = nlist;
+    ix->ivf_count = n;
+    ix->ivf_epoch = ix->epoch;
+    return CODD_KNN_OK;
+}
+
+int codd_knn_ivf_search(codd_knn_index* ix, const float* dev_queries, int B, int k, int nprobe, uint32_t row_base,
+                        uint64_t* dev_keys, float* dev_dist, int64_t* dev_rows, void* stream) {
+    if (!ix || !dev_queries) return fail(CODD_KNN_EINVAL, "null index or queries%s");
+    if (B < 1 || B > CODD_KNN_MAX_BATCH) return fail(CODD_KNN_EINVAL, "B out of range [1,1024]%s");
+    if (k < 1 || k > CODD_KNN_MAX_K) return fail(CODD_KNN_EINVAL, "k out of range [1,128]%s");
+    if (!ix->coarse || ix->ivf_epoch != ix->epoch) return fail(CODD_KNN_EINVAL, "no IVF layout, or rows changed since codd_knn_ivf_install%s");
+    if (nprobe < 1) return fail(CODD_KNN_EINVAL, "nprobe must be >= 1%s");
+    if (nprobe > ix->ivf_nlist) nprobe = ix->ivf_nlist;
+    if (nprobe > CODD_KNN_MAX_K) return fail(CODD_KNN_ENOTSUP, "nprobe above 128 is not supported (probe the whole index with codd_knn_search)%s");
+    DeviceGuard guard(ix->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = ensure_buf(&ix->qn, &ix->qn_cap, (int64_t)B * ix->dpad)) != 0) return rc;
+    if ((rc = ensure_buf(&ix->probe_keys, &ix->probe_cap, (int64_t)B * nprobe)) != 0) return rc;
+    if ((rc = launch_normalize(DT_F32, dev_queries, B, ix->dim, ix->dpad, 1, nullptr, 0, ix->qn, nullptr, st)) != 0) return rc;
+    // 1. coarse: the nprobe best lists per query (exact scan of the centroids, tiny)
+    if ((rc = exact_scan(ix->coarse, ix->qn, B, nprobe, 0u, ix->probe_keys, nullptr, nullptr, st)) != 0) return rc;
+    // 2. scan the probed lists; split each list over several blocks when the batch alone cannot fill the chip
+    int split = (int)((4 * (int64_t)ix->num_cus + (int64_t)B * nprobe - 1) / ((int64_t)B * nprobe));
+    split = split < 1 ? 1 : (split > 16 ? 16 : split);
+    const int64_t m = (int64_t)nprobe * split * k;
+    if ((rc = ensure_buf(&ix->ivf_partial, &ix->ivf_partial_cap, (int64_t)B * m)) != 0) return rc;
+    const int nchunks = ix->dpad / elems_per_chunk(ix->dtype);
+    const int niter = (nchunks + kWave - 1) / kWave;
+    const int slots = k <= 64 ? 1 : 2;
+    const dim3 grid((unsigned)(nprobe * split), (unsigned)B), block(256);
+#define CODD_IVF_LAUNCH(DT, NI, SL)                                                                                          \
+    hipLaunchKernelGGL((ivf_scan_kernel<DT, NI, SL>), grid, block, 0, st, ix->rows_ivf, ix->ivf_ids, ix->ivf_offsets,       \
+                       ix->probe_keys, nprobe, split, ix->dpad, ix->qn, k, row_base, ix->ivf_partial)
+#define CODD_IVF_NITER(DT, SL)                                       \
+    switch (niter) {                                                  \
+        case 1: CODD_IVF_LAUNCH(DT, 1, SL); break;                    \
+        case 2: CODD_IVF_LAUNCH(DT, 2, SL); break;                    \
+        case 3: CODD_IVF_LAUNCH(DT, 3, SL); break;                    \
+        default: CODD_IVF_LAUNCH(DT, 4, SL); break;                   \
+    }
+    {
+        EvScope ev(ix, EV_SCAN, st);
+        if (ix->dtype == DT_F32) { if (slots == 1) { CODD_IVF_NITER(DT_F32, 1) } else { CODD_IVF_NITER(DT_F32, 2) } }
+        else if (ix->dtype == DT_BF16) { if (slots == 1) { CODD_IVF_NITER(DT_BF16, 1) } else { CODD_IVF_NITER(DT_BF16, 2) } }
+        else { if (slots == 1) { CODD_IVF_NITER(DT_F16, 1) } else { CODD_IVF_NITER(DT_F16, 2) } }
+    }
+#undef CODD_IVF_NITER
+#undef CODD_IVF_LAUNCH
+    HIP_TRY(hipGetLastError());
+    // 3. top-k of the nprobe*split partial lists
+    return launch_merge(ix->ivf_partial, B, m, m, k, (u64*)dev_keys, dev_dist, dev_rows, st);
 }
 
 int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {

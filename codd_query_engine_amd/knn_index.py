@@ -162,14 +162,14 @@ class DeviceKnnIndex:
         """Top-k of [B,m] packed keys -> (keys [B,k], dist [B,k], rows [B,k]) on device."""
         return merge_keys(keys, k, self.device)
 
-    def debug_filter_scores(self, queries):
+    def approx_scores(self, queries):
         """Raw approximate scores of the MFMA filter: [256, count] fp32 tensor (diagnostics)."""
         torch = _torch()
         q = self._queries_tensor(queries)
         out = torch.zeros((256, self.count()), dtype=torch.float32, device=self.device)
         native.check(
-            self._lib.codd_knn_debug_filter_scores(self._h, q.data_ptr(), q.shape[0], out.data_ptr(), self._stream()),
-            "codd_knn_debug_filter_scores",
+            self._lib.codd_knn_approx_scores(self._h, q.data_ptr(), q.shape[0], out.data_ptr(), self._stream()),
+            "codd_knn_approx_scores",
         )
         return out
 

@@ -122,12 +122,33 @@ int codd_knn_merge_keys(int device, const uint64_t* dev_keys_in, int B, int m, i
                         uint64_t* dev_keys_out, float* dev_dist, int64_t* dev_rows, void* stream);
 
 /*
- * Diagnostics: the raw approximate (bf16 MFMA) scores of the large-batch filter for B <= 256
- * queries against every stored row: dev_scores[q * count + row], q < 256 (rows of padding
- * queries are zero).  Lets tests check the MFMA operand layouts in isolation.
+ * The raw approximate (bf16 MFMA) scores of B <= 256 queries against every stored row:
+ * dev_scores[q * count + row], q < 256 (rows of padding queries are zero).  Used by the IVF build
+ * (row -> nearest centroid) and by tests that check the MFMA operand layouts in isolation.
  */
-int codd_knn_debug_filter_scores(codd_knn_index* index, const float* dev_queries, int B,
+int codd_knn_approx_scores(codd_knn_index* index, const float* dev_queries, int B,
                                  float* dev_scores, void* stream);
+
+/*
+ * Coarse-IVF with exact scores (BASELINE config 5: the small-batch, HBM-bound regime on corpora
+ * where even one pass over the shard is too slow).  Not on the reference's path — ChromaDB's own
+ * index is HNSW (store.py:63-68) — but the same trade: approximate candidate generation, exact
+ * distances.  The caller clusters the rows (codd_query_engine_amd/ivf.py: spherical k-means whose
+ * assignment GEMM is codd_knn_approx_scores on a centroid index) and hands over
+ *   dev_centroids [nlist][dim] fp32, dev_perm [count] (row slots grouped by list),
+ *   dev_offsets [nlist+1] (list l = perm[offsets[l] .. offsets[l+1])).
+ * install copies the rows into list order (HBM: one more copy of the rows) and builds the coarse
+ * index; any later upsert makes the layout stale (ivf_search then fails with EINVAL).
+ * ivf_search: nprobe (<= 128) best lists per query by exact centroid score, canonical exact scores
+ * over those lists, top-k with ORIGINAL row slots; with nprobe == nlist the result is bit-identical
+ * to codd_knn_search.  Any of dev_keys / dev_dist / dev_rows may be NULL.
+ */
+int codd_knn_copy_rows_f32(const codd_knn_index* index, int64_t first, int64_t n, float* dev_out, void* stream);
+int codd_knn_ivf_install(codd_knn_index* index, const float* dev_centroids, int nlist,
+                         const int64_t* dev_perm, const int64_t* dev_offsets, void* stream);
+int codd_knn_ivf_search(codd_knn_index* index, const float* dev_queries, int B, int k, int nprobe,
+                        uint32_t row_base, uint64_t* dev_keys, float* dev_dist, int64_t* dev_rows,
+                        void* stream);
 
 /*
  * Tuning / introspection (never needed for correctness).

@@ -46,7 +46,7 @@ def test_mfma_scores_match_bf16_reference(Index, n, d, B, dtype):
     raw[:, 0] += 3.0  # asymmetric data: a transposed or permuted operand cannot pass
     q = rng.standard_normal((B, d)).astype(np.float32)
     ix = build(Index, raw, dtype)
-    got = ix.debug_filter_scores(q).cpu().numpy()
+    got = ix.approx_scores(q).cpu().numpy()
     stored = o.widen(o.to_storage(o.normalize_rows(raw), dtype), dtype)
     cb = o.widen(o.to_storage(stored, "bf16"), "bf16").astype(np.float64)
     qb = o.widen(o.to_storage(o.normalize_rows(q), "bf16"), "bf16").astype(np.float64)

@@ -1,0 +1,75 @@
+"""Coarse-IVF + exact scores (BASELINE config 5).  Approximate by design: judged by
+recall@10 against this engine's exact search; exhaustive probing must reproduce it bit for bit."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+
+    assert torch.cuda.is_available()
+    from codd_query_engine_amd import ivf
+    from codd_query_engine_amd.knn_index import DeviceKnnIndex
+
+    return torch, DeviceKnnIndex, ivf
+
+
+def clustered(torch, n, d, centres, seed=7, noise=0.5, centre_seed=7):
+    """Clustered corpus in the spirit of SURVEY §8d row 5: rows = unit centre + noise of norm ~`noise`
+    (cosine to the own centre ~0.9), normalised at ingest.  Queries are drawn the same way."""
+    gc = torch.Generator(device="cuda").manual_seed(centre_seed)
+    c = torch.nn.functional.normalize(torch.randn((centres, d), generator=gc, device="cuda"), dim=1)
+    g = torch.Generator(device="cuda").manual_seed(seed + 1000)
+    which = torch.randint(0, centres, (n,), generator=g, device="cuda")
+    return c[which] + noise * torch.randn((n, d), generator=g, device="cuda") / (d ** 0.5)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_exhaustive_probe_equals_flat_search(env, dtype):
+    torch, Index, ivf = env
+    n, d, nlist = 20_000, 128, 32
+    x = clustered(torch, n, d, 64)
+    ix = Index(d, dtype)
+    ix.upsert_device(0, x.contiguous())
+    stats = ivf.build_ivf(ix, nlist, iters=4)
+    assert stats["rows"] == n and stats["min_list"] >= 0 and stats["max_list"] <= n
+    q = clustered(torch, 9, d, 64, seed=11)
+    for k in (1, 10, 100):
+        d_flat, r_flat = ix.search_tensors(q, k)
+        d_ivf, r_ivf = ivf.search_ivf(ix, q, k, nprobe=nlist)
+        assert torch.equal(r_ivf, r_flat) and torch.equal(d_ivf, d_flat)
+    ix.close()
+
+
+def test_recall_on_clustered_data_and_staleness(env):
+    torch, Index, ivf = env
+    n, d, nlist, k = 200_000, 128, 256, 10
+    x = clustered(torch, n, d, 512)
+    ix = Index(d, "f16")
+    ix.upsert_device(0, x.contiguous())
+    ivf.build_ivf(ix, nlist, iters=6)
+    q = clustered(torch, 64, d, 512, seed=13)
+    _, truth = ix.search_tensors(q, k)
+    recalls = {}
+    for nprobe in (1, 8, 32):
+        _, got = ivf.search_ivf(ix, q, k, nprobe)
+        hit = (got.unsqueeze(2) == truth.unsqueeze(1)).any(dim=2).float().mean().item()
+        recalls[nprobe] = hit
+    assert recalls[1] < recalls[8] <= recalls[32] + 1e-9
+    assert recalls[32] >= 0.95, recalls
+    # distances reported for the hits are the exact canonical ones
+    d_ivf, r_ivf = ivf.search_ivf(ix, q, k, 32)
+    d_flat, r_flat = ix.search_tensors(q, k)
+    same = r_ivf == r_flat
+    assert torch.equal(d_ivf[same], d_flat[same])
+    # a later upsert makes the layout stale: the search refuses instead of answering from old rows
+    ix.upsert_device(5, x[:1].contiguous())
+    from codd_query_engine_amd.native import NativeLibraryError
+
+    with pytest.raises(NativeLibraryError):
+        ivf.search_ivf(ix, q, k, 8)
+    ix.close()
