@@ -139,25 +139,37 @@ __global__ __launch_bounds__(256) void shadow_from_rows_kernel(const void* __res
 // ---------------------------------------------------------------------------------------------
 template <int DT, int NB, int NITER, int SLOTS>
 __global__ __launch_bounds__(256) void scan_topk_kernel(const void* __restrict__ rows_, int64_t n, int dpad,
-                                                        const float* __restrict__ qn, int nq, int k,
+                                                        const float* __restrict__ qn, int nq_arg, int k,
                                                         uint32_t row_base, u64* __restrict__ partial,
-                                                        int64_t partial_stride_q) {
+                                                        int64_t partial_stride_q, const unsigned* __restrict__ qlist,
+                                                        const unsigned* __restrict__ qcount_ptr) {
     typedef RowTraits<DT> RT;
     constexpr int E = RT::E;
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
     const int nchunks = dpad / E;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64* lds = reinterpret_cast<u64*>(smem_raw);
+
+    // Two ways in: (a) the host names a dense group of nq_arg <= NB queries starting at qn (one pass);
+    // (b) LISTED: qcount_ptr / qlist live on the device (the filter's fallback queue) and the kernel walks
+    // the queue NB queries at a time — zero queued queries is the common case and costs one empty launch.
+    const int total = qcount_ptr ? (int)*qcount_ptr : nq_arg;
+    for (int g0 = 0; g0 < total; g0 += NB) {
+    const int nq = total - g0 < NB ? total - g0 : NB;
 
     float qf[NB][NITER][E];
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+    for (int b = 0; b < NB; ++b) {
+        const int64_t qi = b < nq ? (qlist ? (int64_t)qlist[g0 + b] : (int64_t)(g0 + b)) : 0;
 #pragma unroll
         for (int it = 0; it < NITER; ++it) {
             const int j = lane + kWave * it;
 #pragma unroll
             for (int e = 0; e < E; ++e)
-                qf[b][it][e] = (b < nq && j < nchunks) ? qn[(int64_t)b * dpad + (int64_t)j * E + e] : 0.0f;
+                qf[b][it][e] = (b < nq && j < nchunks) ? qn[qi * dpad + (int64_t)j * E + e] : 0.0f;
         }
+    }
 
     WaveTopK<SLOTS> L[NB];
 #pragma unroll
@@ -203,8 +215,6 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const void* __restrict__
     }
 
     // block merge through LDS: [wave][b][slot][lane]
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u64* lds = reinterpret_cast<u64*>(smem_raw);
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -220,13 +230,15 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const void* __restrict__
                 if (s * kWave + lane >= k) cand = 0ull;
                 M.offer_lanes(cand, k, lane);
             }
-        u64* dst = partial + (int64_t)b * partial_stride_q + (int64_t)blockIdx.x * k;
+        u64* dst = partial + (int64_t)(g0 + b) * partial_stride_q + (int64_t)blockIdx.x * k;
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int rank = s * kWave + lane;
             if (rank < k) dst[rank] = M.v[s];
         }
     }
+    __syncthreads();  // the LDS lists are rewritten by the next group
+    }  // group loop
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -237,9 +249,18 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const void* __restrict__
 template <int SLOTS>
 __global__ __launch_bounds__(256) void merge_keys_kernel(const u64* __restrict__ in, int64_t m, int64_t in_stride, int k,
                                                          u64* __restrict__ out_keys, float* __restrict__ out_dist,
-                                                         int64_t* __restrict__ out_rows) {
+                                                         int64_t* __restrict__ out_rows, const unsigned* __restrict__ out_list,
+                                                         const unsigned* __restrict__ count_ptr,
+                                                         unsigned long long* __restrict__ count_total) {
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
+    // LISTED (fallback queue): only the first *count_ptr blocks work, block i answers query out_list[i]
+    if (count_ptr) {
+        const unsigned cnt = *count_ptr;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && count_total && cnt) atomicAdd(count_total, (unsigned long long)cnt);
+        if (blockIdx.x >= cnt) return;
+    }
+    const int64_t oblock = out_list ? (int64_t)out_list[blockIdx.x] : (int64_t)blockIdx.x;
     const u64* src = in + (int64_t)blockIdx.x * in_stride;
     WaveTopK<SLOTS> L;
     L.init();
@@ -265,7 +286,7 @@ __global__ __launch_bounds__(256) void merge_keys_kernel(const u64* __restrict__
         const int rank = s * kWave + lane;
         if (rank < k) {
             const u64 key = L.v[s];
-            const int64_t o = (int64_t)blockIdx.x * k + rank;
+            const int64_t o = oblock * k + rank;
             if (out_keys) out_keys[o] = key;
             if (out_dist) out_dist[o] = key ? 1.0f - key_score(key) : INFINITY;
             if (out_rows) out_rows[o] = key ? (int64_t)key_row(key) : (int64_t)-1;
@@ -390,22 +411,6 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const void* __restrict__ 
     }
 }
 
-// gathers the fallback queries' normalised vectors into a dense block: dst[i] = qn[list[i]]
-__global__ __launch_bounds__(256) void gather_queries_kernel(const float* __restrict__ qn, const unsigned* __restrict__ list,
-                                                             int count, int dpad, float* __restrict__ dst) {
-    const int i = blockIdx.x;
-    if (i >= count) return;
-    const float* src = qn + (int64_t)list[i] * dpad;
-    for (int j = threadIdx.x; j < dpad; j += 256) dst[(int64_t)i * dpad + j] = src[j];
-}
-// scatter the fallback results back: out[list[i]] = src[i]
-__global__ __launch_bounds__(128) void scatter_keys_kernel(const u64* __restrict__ src, const unsigned* __restrict__ list,
-                                                           int count, int k, u64* __restrict__ out) {
-    const int i = blockIdx.x;
-    if (i >= count) return;
-    for (int j = threadIdx.x; j < k; j += 128) out[(int64_t)list[i] * k + j] = src[(int64_t)i * k + j];
-}
-
 }  // namespace
 
 // =============================================================================================
@@ -457,9 +462,8 @@ struct codd_knn_index {
     float* bucket_max = nullptr; int64_t bucket_cap = 0;   // [sample tiles][256]
     u64* hits = nullptr;       int64_t hits_cap = 0;      // [256][hit_cap_q]
     FilterCtl* ctl = nullptr;                              // device
-    FilterCtl* ctl_host = nullptr;                         // pinned host mirror
-    float* qn_fb = nullptr;    int64_t qn_fb_cap = 0;     // gathered fallback queries
-    u64* keys_fb = nullptr;    int64_t keys_fb_cap = 0;
+    u64* fb_partial = nullptr; int64_t fb_partial_cap = 0; // [256][blocks][k] partials of the fallback scan
+    unsigned long long* dstats = nullptr;                  // device counters: hits, survivors, fallback queries
 
     // IVF (optional): rows regrouped by coarse list, original slots, list offsets, the coarse index
     codd_knn_index* coarse = nullptr;  // nlist centroids, f32
@@ -473,7 +477,7 @@ struct codd_knn_index {
     u64* ivf_partial = nullptr; int64_t ivf_partial_cap = 0;
 
     int64_t stat_searches = 0, stat_scan_launches = 0, stat_last_scan_blocks = 0;
-    int64_t stat_filter_passes = 0, stat_fallback_queries = 0, stat_hits = 0, stat_survivors = 0;
+    int64_t stat_filter_passes = 0;
 
     // optional HIP-event timing of the heavy kernels (bench.py's roofline figure): one (start, stop)
     // pair per launch, recorded on the launch stream, read after a sync
@@ -617,14 +621,16 @@ struct ScanArgs {
     uint32_t row_base;
     u64* partial;
     int64_t stride_q;
+    const unsigned* qlist = nullptr;   // LISTED mode (device-side fallback queue)
+    const unsigned* qcount = nullptr;
 };
 
 template <int DT, int NB, int NITER>
 void launch_scan_slots(int slots, dim3 grid, size_t lds, hipStream_t st, const ScanArgs& a) {
     if (slots == 1)
-        hipLaunchKernelGGL((scan_topk_kernel<DT, NB, NITER, 1>), grid, dim3(256), lds, st, a.rows, a.n, a.dpad, a.qn, a.nq, a.k, a.row_base, a.partial, a.stride_q);
+        hipLaunchKernelGGL((scan_topk_kernel<DT, NB, NITER, 1>), grid, dim3(256), lds, st, a.rows, a.n, a.dpad, a.qn, a.nq, a.k, a.row_base, a.partial, a.stride_q, a.qlist, a.qcount);
     else
-        hipLaunchKernelGGL((scan_topk_kernel<DT, NB, NITER, 2>), grid, dim3(256), lds, st, a.rows, a.n, a.dpad, a.qn, a.nq, a.k, a.row_base, a.partial, a.stride_q);
+        hipLaunchKernelGGL((scan_topk_kernel<DT, NB, NITER, 2>), grid, dim3(256), lds, st, a.rows, a.n, a.dpad, a.qn, a.nq, a.k, a.row_base, a.partial, a.stride_q, a.qlist, a.qcount);
 }
 
 template <int DT, int NB>
@@ -651,11 +657,12 @@ int launch_scan_nb(int nb, int niter, int slots, dim3 grid, hipStream_t st, cons
 }
 
 int launch_merge(const u64* in, int B, int64_t m, int64_t in_stride, int k, u64* out_keys, float* out_dist, int64_t* out_rows,
-                 hipStream_t st) {
+                 hipStream_t st, const unsigned* out_list = nullptr, const unsigned* count_ptr = nullptr,
+                 unsigned long long* count_total = nullptr) {
     if (k <= 64)
-        hipLaunchKernelGGL(merge_keys_kernel<1>, dim3(B), dim3(256), 0, st, in, m, in_stride, k, out_keys, out_dist, out_rows);
+        hipLaunchKernelGGL(merge_keys_kernel<1>, dim3(B), dim3(256), 0, st, in, m, in_stride, k, out_keys, out_dist, out_rows, out_list, count_ptr, count_total);
     else
-        hipLaunchKernelGGL(merge_keys_kernel<2>, dim3(B), dim3(256), 0, st, in, m, in_stride, k, out_keys, out_dist, out_rows);
+        hipLaunchKernelGGL(merge_keys_kernel<2>, dim3(B), dim3(256), 0, st, in, m, in_stride, k, out_keys, out_dist, out_rows, out_list, count_ptr, count_total);
     HIP_TRY(hipGetLastError());
     return CODD_KNN_OK;
 }
@@ -721,10 +728,10 @@ void launch_finalize_slots(int slots, int B, hipStream_t st, const codd_knn_inde
     FilterCtl* c = ix->ctl;
     if (slots == 1)
         hipLaunchKernelGGL((finalize_kernel<DT, NITER, 1>), dim3(B), dim3(256), 0, st, ix->rows, ix->dpad, qn, ix->hits, c->hit_cnt,
-                           ix->hit_cap_q, c->flags, k, two_eps, row_base, out_keys, &c->fb_count, c->fb_list, c->stats);
+                           ix->hit_cap_q, c->flags, k, two_eps, row_base, out_keys, &c->fb_count, c->fb_list, ix->dstats);
     else
         hipLaunchKernelGGL((finalize_kernel<DT, NITER, 2>), dim3(B), dim3(256), 0, st, ix->rows, ix->dpad, qn, ix->hits, c->hit_cnt,
-                           ix->hit_cap_q, c->flags, k, two_eps, row_base, out_keys, &c->fb_count, c->fb_list, c->stats);
+                           ix->hit_cap_q, c->flags, k, two_eps, row_base, out_keys, &c->fb_count, c->fb_list, ix->dstats);
 }
 
 template <int DT>
@@ -752,7 +759,10 @@ int ensure_filter_workspace(codd_knn_index* ix) {
     if ((rc = ensure_buf(&ix->hits, &ix->hits_cap, (int64_t)kTileQ * ix->hit_cap_q)) != 0) return rc;
     if (!ix->thr) HIP_TRY(hipMalloc((void**)&ix->thr, kTileQ * sizeof(float)));
     if (!ix->ctl) HIP_TRY(hipMalloc((void**)&ix->ctl, sizeof(FilterCtl)));
-    if (!ix->ctl_host) HIP_TRY(hipHostMalloc((void**)&ix->ctl_host, sizeof(FilterCtl), hipHostMallocDefault));
+    if (!ix->dstats) {
+        HIP_TRY(hipMalloc((void**)&ix->dstats, 4 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(ix->dstats, 0, 4 * sizeof(unsigned long long)));
+    }
     static bool attr_set = false;  // dynamic LDS above 64 KiB needs the opt-in once per process
     if (!attr_set) {
         const void* fns[] = {
@@ -847,21 +857,30 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     }
     if (rc != 0) return rc;
 
-    // the only host round trip of the path: did any query ask for the exact fallback?
-    HIP_TRY(hipMemcpyAsync(ix->ctl_host, ix->ctl, sizeof(FilterCtl), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    ix->stat_hits += ix->ctl_host->stats[0];
-    ix->stat_survivors += ix->ctl_host->stats[1];
-    const int nfb = (int)ix->ctl_host->fb_count;
-    if (nfb > 0) {
-        ix->stat_fallback_queries += nfb;
-        if ((rc = ensure_buf(&ix->qn_fb, &ix->qn_fb_cap, (int64_t)kTileQ * ix->dpad)) != 0) return rc;
-        if ((rc = ensure_buf(&ix->keys_fb, &ix->keys_fb_cap, (int64_t)kTileQ * CODD_KNN_MAX_K)) != 0) return rc;
-        hipLaunchKernelGGL(gather_queries_kernel, dim3(nfb), dim3(256), 0, st, qn, ix->ctl->fb_list, nfb, ix->dpad, ix->qn_fb);
+    // exact-scan fallback for the queries finalize queued (normally none), entirely on the device: the
+    // scan walks the queue (an empty queue costs two empty launches), the merge writes each answer into
+    // its query's slot.  No host round trip: the whole search stays asynchronous on `st`.
+    {
+        int nit;
+        int64_t blocks;
+        if ((rc = scan_geometry(ix, n, &nit, &blocks)) != 0) return rc;
+        if (blocks > ix->num_cus) blocks = ix->num_cus;  // bounds the queue's partial buffer
+        const int64_t stride_q = blocks * k;
+        if ((rc = ensure_buf(&ix->fb_partial, &ix->fb_partial_cap, (int64_t)kTileQ * stride_q)) != 0) return rc;
+        ScanArgs a{ix->rows, n, ix->dpad, qn, 0, k, row_base, ix->fb_partial, stride_q, ix->ctl->fb_list, &ix->ctl->fb_count};
+        {
+            EvScope ev(ix, EV_SCAN, st);
+            switch (ix->dtype) {
+                case DT_F32: rc = launch_scan_nb<DT_F32>(8, nit, slots, dim3((unsigned)blocks), st, a); break;
+                case DT_BF16: rc = launch_scan_nb<DT_BF16>(8, nit, slots, dim3((unsigned)blocks), st, a); break;
+                default: rc = launch_scan_nb<DT_F16>(8, nit, slots, dim3((unsigned)blocks), st, a); break;
+            }
+        }
+        if (rc != 0) return rc;
         HIP_TRY(hipGetLastError());
-        if ((rc = exact_scan(ix, ix->qn_fb, nfb, k, row_base, ix->keys_fb, nullptr, nullptr, st)) != 0) return rc;
-        hipLaunchKernelGGL(scatter_keys_kernel, dim3(nfb), dim3(128), 0, st, ix->keys_fb, ix->ctl->fb_list, nfb, k, keys_out);
-        HIP_TRY(hipGetLastError());
+        if ((rc = launch_merge(ix->fb_partial, kTileQ, stride_q, stride_q, k, keys_out, nullptr, nullptr, st, ix->ctl->fb_list,
+                               &ix->ctl->fb_count, &ix->dstats[2])) != 0)
+            return rc;
     }
     return CODD_KNN_OK;
 }
@@ -892,19 +911,24 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
     if ((rc = ensure_buf(&ix->keys_tmp, &ix->keys_tmp_cap, (int64_t)B * k)) != 0) return rc;
     if ((rc = launch_normalize(DT_F32, dev_queries, B, ix->dim, ix->dpad, 1, nullptr, 0, ix->qn, nullptr, st)) != 0) return rc;
 
+    // the filter passes write keys; when the caller wants only keys (the shard-local half of a sharded
+    // search) they go straight into its buffer and the unpack launch below is skipped
+    const bool keys_only = out_keys && !out_dist && !out_rows;
+    u64* keys_dst = keys_only ? out_keys : ix->keys_tmp;
     if (n == 0) {
         // nothing stored: all-empty result (chromadb returns {"ids": [[]], ...})
-        HIP_TRY(hipMemsetAsync(ix->keys_tmp, 0, (size_t)B * k * sizeof(u64), st));
+        HIP_TRY(hipMemsetAsync(keys_dst, 0, (size_t)B * k * sizeof(u64), st));
     } else if (filter_applies(ix, B, k)) {
         if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
         for (int q0 = 0; q0 < B; q0 += kTileQ) {
             const int nq = B - q0 < kTileQ ? B - q0 : kTileQ;
-            if ((rc = filter_pass(ix, ix->qn + (int64_t)q0 * ix->dpad, nq, k, row_base, ix->keys_tmp + (int64_t)q0 * k, st)) != 0) return rc;
+            if ((rc = filter_pass(ix, ix->qn + (int64_t)q0 * ix->dpad, nq, k, row_base, keys_dst + (int64_t)q0 * k, st)) != 0) return rc;
         }
     } else {
         // small batches: the per-block partials merge straight into the caller's buffers
         return exact_scan(ix, ix->qn, B, k, row_base, out_keys, out_dist, out_rows, st);
     }
+    if (keys_only) return CODD_KNN_OK;
     // unpack (m == k: the merge kernel is the identity on a sorted list)
     return launch_merge(ix->keys_tmp, B, k, k, k, out_keys, out_dist, out_rows, st);
 }
@@ -946,14 +970,13 @@ int codd_knn_destroy(codd_knn_index* ix) {
     DeviceGuard guard(ix->device);
     (void)hipDeviceSynchronize();
     void* bufs[] = {ix->rows, ix->shadow, ix->qn, ix->partial, ix->keys_tmp, ix->qfrag, ix->thr, ix->bucket_max,
-                    ix->hits, ix->ctl, ix->qn_fb, ix->keys_fb};
+                    ix->hits, ix->ctl, ix->fb_partial, ix->dstats};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     void* ivf_bufs[] = {ix->rows_ivf, ix->ivf_ids, ix->ivf_offsets, ix->probe_keys, ix->ivf_partial};
     for (void* b : ivf_bufs)
         if (b) (void)hipFree(b);
     if (ix->coarse) (void)codd_knn_destroy(ix->coarse);
-    if (ix->ctl_host) (void)hipHostFree(ix->ctl_host);
     for (hipEvent_t e : ix->ev) (void)hipEventDestroy(e);
     delete ix;
     return CODD_KNN_OK;
@@ -1286,9 +1309,16 @@ int codd_knn_get_stat(const codd_knn_index* ix, const char* key, int64_t* out) {
     else if (strcmp(key, "scan_launches") == 0) *out = ix->stat_scan_launches;
     else if (strcmp(key, "last_scan_blocks") == 0) *out = ix->stat_last_scan_blocks;
     else if (strcmp(key, "filter_passes") == 0) *out = ix->stat_filter_passes;
-    else if (strcmp(key, "fallback_queries") == 0) *out = ix->stat_fallback_queries;
-    else if (strcmp(key, "filter_hits") == 0) *out = ix->stat_hits;
-    else if (strcmp(key, "filter_survivors") == 0) *out = ix->stat_survivors;
+    else if (strcmp(key, "fallback_queries") == 0 || strcmp(key, "filter_hits") == 0 || strcmp(key, "filter_survivors") == 0) {
+        // device-side counters (the search itself never reads them back): synchronises
+        unsigned long long h[4] = {0, 0, 0, 0};
+        if (ix->dstats) {
+            DeviceGuard guard(ix->device);
+            HIP_TRY(hipDeviceSynchronize());
+            HIP_TRY(hipMemcpy(h, ix->dstats, sizeof(h), hipMemcpyDeviceToHost));
+        }
+        *out = (int64_t)(key[0] == 'f' && key[1] == 'a' ? h[2] : (strcmp(key, "filter_hits") == 0 ? h[0] : h[1]));
+    }
     else if (strcmp(key, "capacity_rows") == 0) *out = ix->capacity;
     else if (strcmp(key, "num_cus") == 0) *out = ix->num_cus;
     else if (strcmp(key, "device_bytes") == 0)

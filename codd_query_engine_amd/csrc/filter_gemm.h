@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
                                                        int cap_q, unsigned* __restrict__ flags, int k, float two_eps,
                                                        uint32_t row_base, u64* __restrict__ out_keys,
                                                        unsigned* __restrict__ fb_count, unsigned* __restrict__ fb_list,
-                                                       unsigned* __restrict__ stats) {
+                                                       unsigned long long* __restrict__ stats) {
     typedef RowTraits<DT> RT;
     constexpr int E = RT::E;
     __shared__ u64 lds_list[4 * SLOTS * kWave];
@@ -510,8 +510,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
         return;
     }
     if (tid == 0 && stats) {
-        atomicAdd(&stats[0], total);
-        atomicAdd(&stats[1], ns);
+        atomicAdd(&stats[0], (unsigned long long)total);
+        atomicAdd(&stats[1], (unsigned long long)ns);
     }
 
     // 3. exact canonical scores of the survivors (one wave per row)
