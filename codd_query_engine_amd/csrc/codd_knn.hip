@@ -18,6 +18,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <atomic>
 #include <new>
 #include <vector>
 
@@ -716,10 +717,13 @@ int exact_scan(codd_knn_index* ix, const float* qn, int nqueries, int k, uint32_
 // ---- filter path -----------------------------------------------------------------------------
 
 float filter_eps(const codd_knn_index* ix) {
-    // |approx - exact| <= (2^-8 + 2^-16) |q||c| for bf16-rounded q and c (2^-9 each, Cauchy-Schwarz),
-    // 2^-9 when the stored rows already are bf16; + 1e-4 for the two fp32 accumulations; unit norms.
+    // |approx - exact| for unit-norm q and c:
+    //   rounding  : (2^-8 + 2^-16) when q and the stored row are both rounded to bf16 (2^-9 relative each,
+    //               Cauchy-Schwarz over the element-wise errors); 2^-9 when the stored rows already are bf16;
+    //   summation : two fp32 accumulations of <= dpad terms whose magnitudes sum to <= 1: dpad * 2^-24 each.
     const float rounding = ix->dtype == DT_BF16 ? 0.001953125f : 0.00392151f;
-    return (rounding + 1.0e-4f) * 1.001f;
+    const float summation = (float)ix->dpad * 1.1920929e-7f;  // dpad * 2^-23
+    return (rounding + summation) * 1.001f;
 }
 
 template <int DT, int NITER>
@@ -763,8 +767,8 @@ int ensure_filter_workspace(codd_knn_index* ix) {
         HIP_TRY(hipMalloc((void**)&ix->dstats, 4 * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(ix->dstats, 0, 4 * sizeof(unsigned long long)));
     }
-    static bool attr_set = false;  // dynamic LDS above 64 KiB needs the opt-in once per process
-    if (!attr_set) {
+    static std::atomic<bool> attr_set{false};  // dynamic LDS above 64 KiB needs the opt-in (idempotent)
+    if (!attr_set.load(std::memory_order_acquire)) {
         const void* fns[] = {
             (const void*)&gemm_filter_kernel<MODE_FILTER, 1>, (const void*)&gemm_filter_kernel<MODE_FILTER, 2>,
             (const void*)&gemm_filter_kernel<MODE_FILTER, 4>, (const void*)&gemm_filter_kernel<MODE_FILTER, 8>,
@@ -773,7 +777,7 @@ int ensure_filter_workspace(codd_knn_index* ix) {
             (const void*)&gemm_filter_kernel<MODE_DUMP, 8>};
         for (const void* fn : fns)
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter_lds_bytes(MODE_FILTER)));
-        attr_set = true;
+        attr_set.store(true, std::memory_order_release);
     }
     return CODD_KNN_OK;
 }

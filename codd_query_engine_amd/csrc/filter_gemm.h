@@ -43,6 +43,31 @@ constexpr int kRB = CODD_RB;
 constexpr int kFilterWaves = 8 / kRB;
 constexpr int kFilterThreads = 64 * kFilterWaves;
 constexpr int kQP = kStagePieces / kFilterThreads;  // query-slice pieces each thread stages per K-step
+#ifndef CODD_MFMA16
+#define CODD_MFMA16 1        // 1: v_mfma_f32_16x16x32_bf16 (16-row x 16-query blocks, K 32) instead of 32x32x16
+#endif
+// MFMA block geometry.  32x32x16: a wave's 32 rows are ONE row block, a 64-wide K-step is 4 sub-steps, a
+// 32-query block per accumulator (16 regs).  16x16x32: TWO row blocks of 16, 2 sub-steps, 16-query blocks
+// (4 regs).  Either way a wave-level operand piece is 64 lanes x 16 B = 1 KiB and an accumulator set is 128 regs.
+constexpr int kMB = CODD_MFMA16 ? 16 : 32;         // rows (and queries) per MFMA block
+constexpr int kAccRegs = CODD_MFMA16 ? 4 : 16;
+constexpr int kKS = CODD_MFMA16 ? 2 : 4;           // MFMA K sub-steps per 64-wide K-step
+constexpr int kRS = (32 / kMB) * kRB;              // row blocks per wave
+constexpr int kQBper32 = 32 / kMB;                 // query blocks per 32 queries
+static_assert(!(CODD_MFMA16 && CODD_RB != 1), "the 16x16x32 shape is only built with one 32-row block per wave");
+#if CODD_MFMA16
+typedef __attribute__((ext_vector_type(4))) float acc_t;
+#else
+typedef __attribute__((ext_vector_type(16))) float acc_t;
+#endif
+// which of the 4 corpus pieces of a (32-row block, K-step) feeds row block rs at sub-step ks
+__host__ __device__ constexpr int a_piece(int rs_in_block, int ks) { return CODD_MFMA16 ? rs_in_block * 2 + ks : ks; }
+// which piece of a query K-slice feeds query block qb at sub-step ks
+__host__ __device__ constexpr int b_piece(int qb, int ks) { return CODD_MFMA16 ? qb * 2 + ks : qb * 4 + ks; }
+// accumulator register r of a lane -> row offset inside the MFMA row block
+__device__ __forceinline__ int acc_row(int r, int lane) {
+    return CODD_MFMA16 ? 4 * (lane >> 4) + r : 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+}
 // build-time experiment switches (defaults = the shipped configuration)
 #ifndef CODD_QS
 #define CODD_QS 2            // 64-wide query K-slices per LDS stage = K-steps per workgroup barrier
@@ -94,16 +119,29 @@ enum { MODE_FILTER = 0, MODE_SAMPLE = 1, MODE_DUMP = 2 };
 // flags[] words shared with the host
 enum { FLAG_WG_OVERFLOW = 0, FLAG_NEED_FALLBACK = 1, FLAG_WORDS = 4 };
 
+// 16-byte piece (8 consecutive elements, c8 = element/8) of `row` in the shadow / of query q in qfrag.
+// 32x32x16: lane (h = lane>>5, r = lane&31) of sub-step kk holds k = 64s + 32h + 8kk + 0..7
+// 16x16x32: lane (kq = lane>>4, r = lane&15) of sub-step ks holds k = 64s + 32ks + 8kq + 0..7
 __host__ __device__ inline int64_t shadow_piece_index(int64_t row, int c8, int nsteps) {
     const int64_t block = row >> 5;
-    const int r = (int)(row & 31);
-    const int s = c8 >> 3, h = (c8 >> 2) & 1, kk = c8 & 3;
+    const int s = c8 >> 3;
+#if CODD_MFMA16
+    const int rs = (int)(row >> 4) & 1, r = (int)(row & 15), ks = (c8 >> 2) & 1, kq = c8 & 3;
+    return ((block * nsteps + s) * 4 + a_piece(rs, ks)) * 64 + (kq * 16 + r);
+#else
+    const int r = (int)(row & 31), h = (c8 >> 2) & 1, kk = c8 & 3;
     return ((block * nsteps + s) * 4 + kk) * 64 + (h * 32 + r);
+#endif
 }
 __host__ __device__ inline int64_t qfrag_piece_index(int q, int c8) {
-    const int nb = q >> 5, c = q & 31;
-    const int s = c8 >> 3, h = (c8 >> 2) & 1, kk = c8 & 3;
+    const int s = c8 >> 3;
+#if CODD_MFMA16
+    const int qb = q >> 4, c = q & 15, ks = (c8 >> 2) & 1, kq = c8 & 3;
+    return ((int64_t)s * 32 + b_piece(qb, ks)) * 64 + (kq * 16 + c);
+#else
+    const int nb = q >> 5, c = q & 31, h = (c8 >> 2) & 1, kk = c8 & 3;
     return (((int64_t)s * 8 + nb) * 4 + kk) * 64 + (h * 32 + c);
+#endif
 }
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
@@ -158,7 +196,7 @@ __global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_
     unsigned* lds_hits = lds_w + 320;                                    // kHitCap x 3 dwords (FILTER only)
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = lane & 31, h = lane >> 5;
+    const int c = lane & (kMB - 1);  // query inside an MFMA query block
 
     const int64_t G = gridDim.x;
     const int64_t my_tiles = ntiles_run > (int64_t)blockIdx.x ? (ntiles_run - blockIdx.x + G - 1) / G : 0;
@@ -174,13 +212,14 @@ __global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_
 
     constexpr int kSP = NBQ * 256;  // 16-byte pieces of a query slice that are actually staged
     constexpr int kQPn = kSP / kFilterThreads > 0 ? kSP / kFilterThreads : 1;
-    f32x16 acc[kRB][NBQ];
+    constexpr int NQB = NBQ * kQBper32;  // MFMA query blocks
+    acc_t acc[kRS][NQB];
 #pragma unroll
-    for (int rb = 0; rb < kRB; ++rb)
+    for (int rs = 0; rs < kRS; ++rs)
 #pragma unroll
-        for (int nb = 0; nb < NBQ; ++nb)
+        for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[rb][nb][i] = 0.0f;
+            for (int i = 0; i < kAccRegs; ++i) acc[rs][qb][i] = 0.0f;
 
     // load cursor (runs kPrefetch steps ahead of the compute cursor)
     int64_t l_u = blockIdx.x;  // run-tile ordinal
@@ -268,16 +307,23 @@ __global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_
 #if CODD_MFMA_PRIO
             __builtin_amdgcn_s_setprio(1);
 #endif
+            constexpr int kNqbRun = (CODD_EXP_NB < NBQ ? CODD_EXP_NB : NBQ) * kQBper32;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            for (int ks = 0; ks < kKS; ++ks) {
 #pragma unroll
-                for (int nb = 0; nb < (CODD_EXP_NB < NBQ ? CODD_EXP_NB : NBQ); ++nb) {
-                    const bf16x8 b = CODD_EXP_NO_LDSREAD ? __builtin_bit_cast(bf16x8, ring[i][0][(kk + nb) & 3])
-                                                         : __builtin_bit_cast(bf16x8, qs[(nb * 4 + kk) * 64]);
+                for (int qb = 0; qb < kNqbRun; ++qb) {
+                    const bf16x8 b = CODD_EXP_NO_LDSREAD ? __builtin_bit_cast(bf16x8, ring[i][0][(ks + qb) & 3])
+                                                         : __builtin_bit_cast(bf16x8, qs[b_piece(qb, ks) * 64]);
 #pragma unroll
-                    for (int rb = 0; rb < kRB; ++rb)
-                        acc[rb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ring[i][rb][kk]), b,
-                                                                              acc[rb][nb], 0, 0, 0);
+                    for (int rs = 0; rs < kRS; ++rs) {
+                        // row block rs lives in 32-row block rs / (32/kMB), sub-block rs % (32/kMB)
+                        const bf16x8 a = __builtin_bit_cast(bf16x8, ring[i][rs / kQBper32][a_piece(rs % kQBper32, ks)]);
+#if CODD_MFMA16
+                        acc[rs][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[rs][qb], 0, 0, 0);
+#else
+                        acc[rs][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[rs][qb], 0, 0, 0);
+#endif
+                    }
                 }
             }
 #if CODD_MFMA_PRIO
@@ -287,15 +333,14 @@ __global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_
             // pin the step's shape: all 8 global loads (4 query, 4 corpus) first so they fly under the
             // MFMAs; at most a few query fragments live (4 LDS reads up front, then one per MFMA);
             // the LDS writes of the next query slice last
-            constexpr int kNbRun = CODD_EXP_NB < NBQ ? CODD_EXP_NB : NBQ;
             __builtin_amdgcn_sched_group_barrier(0x020, 4 * kRB + (CODD_EXP_NO_QSTAGE ? 0 : kQPn), 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
-            for (int g = 0; g < 4 * kNbRun - 4; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, kRB, 0);
+            for (int g = 0; g < kKS * kNqbRun - 4; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, kRS, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * kRB, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * kRS, 0);
             if (!CODD_EXP_NO_QSTAGE) __builtin_amdgcn_sched_group_barrier(0x200, kQPn, 0);
 #endif
             {
@@ -312,66 +357,66 @@ __global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_
                 const int64_t tile = c_u * tile_stride;
                 const bool ragged = (tile + 1) * kTileRows > n;
 #pragma unroll
-                for (int rb = 0; rb < kRB; ++rb) {
-                const int64_t row0 = tile * kTileRows + (wave * kRB + rb) * 32 + 4 * h;  // + (reg&3) + 8*(reg>>2)
-                if (MODE == MODE_FILTER) {
+                for (int rs = 0; rs < kRS; ++rs) {
+                    const int64_t row0 = tile * kTileRows + wave * (32 * kRB) + rs * kMB;  // + acc_row(r, lane)
+                    if (MODE == MODE_FILTER) {
 #pragma unroll
-                    for (int nb = 0; nb < NBQ; ++nb) {
-                        const float th = CODD_EXP_NO_HITS ? INFINITY : __uint_as_float(lds_w[nb * 32 + c]);
-                        float m = acc[rb][nb][0];
+                        for (int qb = 0; qb < NQB; ++qb) {
+                            const float th = CODD_EXP_NO_HITS ? INFINITY : __uint_as_float(lds_w[qb * kMB + c]);
+                            float m = acc[rs][qb][0];
 #pragma unroll
-                        for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[rb][nb][r]);
-                        if (__any(m >= th)) {
+                            for (int r = 1; r < kAccRegs; ++r) m = fmaxf(m, acc[rs][qb][r]);
+                            if (__any(m >= th)) {
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const float v = acc[rb][nb][r];
-                                const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
-                                if (v >= th && row < n) {
-                                    const unsigned slot = atomicAdd(&lds_w[256], 1u);
-                                    if (slot < (unsigned)kHitCap) {
-                                        lds_hits[slot * 3 + 0] = __float_as_uint(v);
-                                        lds_hits[slot * 3 + 1] = (unsigned)row;
-                                        lds_hits[slot * 3 + 2] = (unsigned)(nb * 32 + c);
-                                    } else {
-                                        // list full (> kHitCap/2 hits inside ONE tile): this query's candidates
-                                        // are incomplete -> poison its counter (top bit: reads as "> cap" and can
-                                        // never wrap) so that finalize sends exactly this query to the exact scan
-                                        atomicOr(&hit_cnt[nb * 32 + c], 0x80000000u);
+                                for (int r = 0; r < kAccRegs; ++r) {
+                                    const float v = acc[rs][qb][r];
+                                    const int64_t row = row0 + acc_row(r, lane);
+                                    if (v >= th && row < n) {
+                                        const unsigned slot = atomicAdd(&lds_w[256], 1u);
+                                        if (slot < (unsigned)kHitCap) {
+                                            lds_hits[slot * 3 + 0] = __float_as_uint(v);
+                                            lds_hits[slot * 3 + 1] = (unsigned)row;
+                                            lds_hits[slot * 3 + 2] = (unsigned)(qb * kMB + c);
+                                        } else {
+                                            // list full (> kHitCap/2 hits inside ONE tile): this query's candidates
+                                            // are incomplete -> poison its counter (top bit: reads as "> cap" and can
+                                            // never wrap) so that finalize sends exactly this query to the exact scan
+                                            atomicOr(&hit_cnt[qb * kMB + c], 0x80000000u);
+                                        }
                                     }
                                 }
                             }
                         }
-                    }
-                } else if (MODE == MODE_SAMPLE) {
+                    } else if (MODE == MODE_SAMPLE) {
 #pragma unroll
-                    for (int nb = 0; nb < NBQ; ++nb) {
-                        float m = -INFINITY;
+                        for (int qb = 0; qb < NQB; ++qb) {
+                            float m = -INFINITY;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
-                            const float v = (!ragged || row < n) ? acc[rb][nb][r] : -INFINITY;
-                            m = fmaxf(m, v);
+                            for (int r = 0; r < kAccRegs; ++r) {
+                                const int64_t row = row0 + acc_row(r, lane);
+                                const float v = (!ragged || row < n) ? acc[rs][qb][r] : -INFINITY;
+                                m = fmaxf(m, v);
+                            }
+                            atomicMax(&lds_w[qb * kMB + c], ord_f32(m));
                         }
-                        atomicMax(&lds_w[nb * 32 + c], ord_f32(m));
+                    } else {
+#pragma unroll
+                        for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                            for (int r = 0; r < kAccRegs; ++r) {
+                                const int64_t row = row0 + acc_row(r, lane);
+                                if (row < n) dump[(int64_t)(qb * kMB + c) * n + row] = acc[rs][qb][r];
+                            }
                     }
-                } else {
-#pragma unroll
-                    for (int nb = 0; nb < NBQ; ++nb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int64_t row = row0 + (r & 3) + 8 * (r >> 2);
-                            if (row < n) dump[(int64_t)(nb * 32 + c) * n + row] = acc[rb][nb][r];
-                        }
-                }
-            }  // rb
+                }  // rs
             }
             if (tile_end) {
 #pragma unroll
-                for (int rb = 0; rb < kRB; ++rb)
+                for (int rs = 0; rs < kRS; ++rs)
 #pragma unroll
-                    for (int nb = 0; nb < NBQ; ++nb)
+                    for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[rb][nb][r] = 0.0f;
+                        for (int r = 0; r < kAccRegs; ++r) acc[rs][qb][r] = 0.0f;
             }
             // stage boundary: the other stage is complete and this one is free to be overwritten.
             // A tile end synchronises too (its bookkeeping below needs every wave's epilogue done).

@@ -18,8 +18,8 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "base": {},
-    "nt": {"CODD_NT_LOADS": 1},
-    "nt_ring2": {"CODD_NT_LOADS": 1, "CODD_RING": 2},
+    "mfma16": {"CODD_MFMA16": 1},
+    "mfma16_ring2": {"CODD_MFMA16": 1, "CODD_RING": 2},
 }
 
 
