@@ -4,26 +4,29 @@
 // survivors are re-scored exactly (canonical fp32) by finalize_kernel.
 //
 // Data layout (both operands are stored in MFMA-fragment order, so every wave-level load is one
-// contiguous 1 KiB piece and LDS reads are conflict-free without a swizzle):
+// contiguous 1 KiB piece and LDS reads are conflict-free without a swizzle); shown for the shipped
+// v_mfma_f32_16x16x32_bf16 shape (shadow_piece_index / qfrag_piece_index are the definition; the
+// 32x32x16 order is kept behind -DCODD_MFMA16=0):
 //
 //   shadow (bf16 copy of the corpus, written at ingest), in 16-byte pieces of 8 elements:
-//       piece[((block*nsteps + s)*4 + kk)*64 + (h*32 + r)] = C[row = 32*block + r][k = 64s + 32h + 8kk + 0..7]
+//       piece[((block*nsteps + s)*4 + (rs*2 + ks))*64 + (kq*16 + r)]
+//                                   = C[row = 32*block + 16*rs + r][k = 64s + 32ks + 8kq + 0..7]
 //   qfrag (bf16 query block, written by qfrag_kernel per search):
-//       piece[((s*8 + nb)*4 + kk)*64 + (h*32 + c)]         = Q[query = 32*nb + c][k = 64s + 32h + 8kk + 0..7]
+//       piece[(s*32 + qb*2 + ks)*64 + (kq*16 + c)] = Q[query = 16*qb + c][k = 64s + 32ks + 8kq + 0..7]
 //
-// One v_mfma_f32_32x32x16_bf16 consumes, per lane (r|c = lane&31, h = lane>>5), exactly one such
-// piece of each operand; the k order inside an instruction is permuted identically on both sides,
-// which a dot product does not notice.
+// One MFMA consumes, per lane (r|c = lane&15, kq = lane>>4), exactly one such piece of each operand;
+// the k order inside an instruction is permuted identically on both sides, which a dot product does
+// not notice.
 //
 // Workgroup = 8 waves = one tile of 256 corpus rows x 256 queries, K-step 64:
-//   * wave w owns corpus rows [32w, 32w+32) of the tile and ALL 256 queries: 8 accumulator blocks
-//     of 32x32 (128 VGPRs).  Its corpus fragments go HBM -> registers directly (each corpus byte
+//   * wave w owns corpus rows [32w, 32w+32) of the tile and ALL 256 queries: 2 x 16 accumulator blocks
+//     of 16x16 (128 VGPRs).  Its corpus fragments go HBM -> registers directly (each corpus byte
 //     enters the CU once, is used by one wave: no LDS round trip), three K-steps deep in a
 //     register ring so ~12 KiB per wave stays in flight;
-//   * the query K-slice (32 KiB, L2-resident, shared by the 8 waves) is double-buffered in LDS,
-//     staged through registers (issue early, write late) so that every load in the kernel is an
-//     ordinary counted load and __syncthreads() stays a bare s_barrier;
-//   * one barrier per K-step; 32 MFMAs + 32 ds_read_b128 per wave per K-step.
+//   * the query K-slice (32 KiB, L2-resident, shared by the 8 waves) is double-buffered in LDS in
+//     stages of two slices, staged through registers (issue early, write late) so that every load in
+//     the kernel is an ordinary counted load and __syncthreads() stays a bare s_barrier;
+//   * one barrier per stage; 64 MFMAs + 32 ds_read_b128 per wave per K-step.
 #pragma once
 #include "row_traits.h"
 #include "wave_topk.h"
