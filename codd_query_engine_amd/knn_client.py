@@ -100,6 +100,8 @@ class Collection:
         n = len(ids)
         if n == 0:
             return
+        if any(not isinstance(i, str) or not i for i in ids):
+            raise ValueError("ids must be non-empty strings")
         if len(set(ids)) != n:
             raise ValueError("duplicate ids in one upsert")
         for name, seq in (("metadatas", metadatas), ("documents", documents)):
@@ -119,8 +121,6 @@ class Collection:
         next_slot = len(self._ids)
         fresh = []
         for i, doc_id in enumerate(ids):
-            if not isinstance(doc_id, str) or not doc_id:
-                raise ValueError("ids must be non-empty strings")
             slot = self._slot_of.get(doc_id)
             if slot is None:
                 slot = next_slot
