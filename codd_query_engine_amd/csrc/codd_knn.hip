@@ -88,7 +88,8 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 hb[e] = DT == DT_BF16 ? f32_to_bf16_rne(v[e]) : f32_to_f16_rne(v[e]);
-                if (DT == DT_F16) v[e] = f16_bits_to_f32(hb[e]);  // the shadow approximates the STORED value
+                // the shadow approximates the STORED value, whatever the shadow element type is
+                v[e] = DT == DT_F16 ? f16_bits_to_f32(hb[e]) : __uint_as_float((uint32_t)hb[e] << 16);
             }
             uint2* o = reinterpret_cast<uint2*>(out_) + orow * (int64_t)nch + j;
             *o = make_uint2((uint32_t)hb[0] | ((uint32_t)hb[1] << 16), (uint32_t)hb[2] | ((uint32_t)hb[3] << 16));
@@ -717,13 +718,26 @@ int exact_scan(codd_knn_index* ix, const float* qn, int nqueries, int k, uint32_
 // ---- filter path -----------------------------------------------------------------------------
 
 float filter_eps(const codd_knn_index* ix) {
-    // |approx - exact| for unit-norm q and c:
-    //   rounding  : (2^-8 + 2^-16) when q and the stored row are both rounded to bf16 (2^-9 relative each,
-    //               Cauchy-Schwarz over the element-wise errors); 2^-9 when the stored rows already are bf16;
+    // |approx - exact| for unit-norm q and c.  u = unit roundoff of the shadow element type
+    // (bf16: 2^-9, fp16: 2^-11):
+    //   rounding  : (2u + u^2) when q and the stored row are both rounded (Cauchy-Schwarz over the
+    //               element-wise relative errors); u when the stored rows already are exactly
+    //               representable (bf16 rows under a bf16 shadow, f16 rows under an fp16 shadow);
+    //   subnormal : fp16 only — below 2^-14 the grid is absolute (2^-25 per element, <= sqrt(dpad) * 2^-25
+    //               per operand after Cauchy-Schwarz against a unit vector);
     //   summation : two fp32 accumulations of <= dpad terms whose magnitudes sum to <= 1: dpad * 2^-24 each.
-    const float rounding = ix->dtype == DT_BF16 ? 0.001953125f : 0.00392151f;
+#if CODD_SHADOW_F16
+    const float u = 4.8828125e-4f;
+    const bool exact_rows = ix->dtype == DT_F16;
+    const float subnormal = 2.0f * sqrtf((float)ix->dpad) * 2.9802322e-8f;
+#else
+    const float u = 0.001953125f;
+    const bool exact_rows = ix->dtype == DT_BF16;
+    const float subnormal = 0.0f;
+#endif
+    const float rounding = exact_rows ? u : 2.0f * u + u * u;
     const float summation = (float)ix->dpad * 1.1920929e-7f;  // dpad * 2^-23
-    return (rounding + summation) * 1.001f;
+    return (rounding + subnormal + summation) * 1.001f;
 }
 
 template <int DT, int NITER>
@@ -941,7 +955,19 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
 
 extern "C" {
 
-const char* codd_knn_version(void) { return "codd_knn 0.2.0 gfx950"; }
+const char* codd_knn_version(void) {
+    return "codd_knn 0.3.0 gfx950"
+#if CODD_SHADOW_F16
+           " shadow=f16"
+#else
+           " shadow=bf16"
+#endif
+#if CODD_MFMA16
+           " mfma=16x16x32";
+#else
+           " mfma=32x32x16";
+#endif
+}
 const char* codd_knn_last_error(void) { return g_err; }
 
 int codd_knn_create(codd_knn_index** out, int device, int dim, int dtype, int metric) {

@@ -33,7 +33,14 @@
 
 namespace codd {
 
+#ifndef CODD_SHADOW_F16
+#define CODD_SHADOW_F16 0    // 1: the filter's operands are fp16 (11-bit significand: eps ~4x tighter) instead of bf16
+#endif
+#if CODD_SHADOW_F16
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8;  // "shadow element x8" (name kept for the bf16 default)
+#else
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+#endif
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int kTileRows = 256;
@@ -147,7 +154,13 @@ __host__ __device__ inline int64_t qfrag_piece_index(int q, int c8) {
 #endif
 }
 
+// two fp32 values -> two shadow elements (bf16, or fp16 under CODD_SHADOW_F16), round to nearest even
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+#if CODD_SHADOW_F16
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 v = {(_Float16)lo, (_Float16)hi};  // v_cvt_f16_f32, RNE; |x| <= 1 here, no overflow
+    return __builtin_bit_cast(uint32_t, v);
+#endif
     uint32_t a = __float_as_uint(lo), b = __float_as_uint(hi);
     a = ((a & 0x7fffffffu) > 0x7f800000u) ? ((a >> 16) | 0x0040u) : ((a + 0x7fffu + ((a >> 16) & 1u)) >> 16);
     b = ((b & 0x7fffffffu) > 0x7f800000u) ? ((b >> 16) | 0x0040u) : ((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
@@ -321,8 +334,12 @@ __global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_
                     for (int rs = 0; rs < kRS; ++rs) {
                         // row block rs lives in 32-row block rs / (32/kMB), sub-block rs % (32/kMB)
                         const bf16x8 a = __builtin_bit_cast(bf16x8, ring[i][rs / kQBper32][a_piece(rs % kQBper32, ks)]);
-#if CODD_MFMA16
+#if CODD_MFMA16 && CODD_SHADOW_F16
+                        acc[rs][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[rs][qb], 0, 0, 0);
+#elif CODD_MFMA16
                         acc[rs][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[rs][qb], 0, 0, 0);
+#elif CODD_SHADOW_F16
+                        acc[rs][qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[rs][qb], 0, 0, 0);
 #else
                         acc[rs][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[rs][qb], 0, 0, 0);
 #endif

@@ -52,7 +52,7 @@ extern "C" {
 
 typedef struct codd_knn_index codd_knn_index;
 
-/* library / build identification: "codd_knn <semver> gfx950" */
+/* library / build identification: "codd_knn <semver> gfx950 shadow=<bf16|f16> mfma=<shape>" */
 const char* codd_knn_version(void);
 const char* codd_knn_last_error(void);
 

@@ -18,8 +18,7 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "base": {},
-    "mfma16": {"CODD_MFMA16": 1},
-    "mfma16_ring2": {"CODD_MFMA16": 1, "CODD_RING": 2},
+    "f16shadow": {"CODD_SHADOW_F16": 1},
 }
 
 

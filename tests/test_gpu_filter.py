@@ -38,18 +38,22 @@ def oracle_answer(raw, q_raw, k, dtype):
 
 
 @pytest.mark.parametrize("n,d,B,dtype", [(1000, 768, 40, "f32"), (300, 128, 256, "f32"), (700, 384, 7, "bf16"), (513, 1024, 33, "f16")])
-def test_mfma_scores_match_bf16_reference(Index, n, d, B, dtype):
-    """Operand layouts: every approximate score equals the dot product of the bf16-rounded stored
-    row and bf16-rounded query (fp32 accumulation order aside)."""
+def test_mfma_scores_match_rounded_operand_reference(Index, n, d, B, dtype):
+    """Operand layouts: every approximate score equals the dot product of the stored row and the query,
+    both rounded to the shadow element type (bf16, or fp16 in a CODD_SHADOW_F16 build), fp32
+    accumulation order aside."""
     rng = np.random.default_rng(n + d)
     raw = rng.standard_normal((n, d)).astype(np.float32)
     raw[:, 0] += 3.0  # asymmetric data: a transposed or permuted operand cannot pass
     q = rng.standard_normal((B, d)).astype(np.float32)
     ix = build(Index, raw, dtype)
     got = ix.approx_scores(q).cpu().numpy()
+    from codd_query_engine_amd import native
+
+    shadow = "f16" if "shadow=f16" in native.load().codd_knn_version().decode() else "bf16"
     stored = o.widen(o.to_storage(o.normalize_rows(raw), dtype), dtype)
-    cb = o.widen(o.to_storage(stored, "bf16"), "bf16").astype(np.float64)
-    qb = o.widen(o.to_storage(o.normalize_rows(q), "bf16"), "bf16").astype(np.float64)
+    cb = o.widen(o.to_storage(stored, shadow), shadow).astype(np.float64)
+    qb = o.widen(o.to_storage(o.normalize_rows(q), shadow), shadow).astype(np.float64)
     ref = qb @ cb.T
     assert got.shape == (256, n)
     assert np.abs(got[:B] - ref).max() < 2e-5
