@@ -448,9 +448,9 @@ struct codd_knn_index {
 
     // filter path knobs
     int filter_enabled = 1;
-    int64_t filter_min_rows = 32768;
-    int64_t filter_min_rows_small = 500000;  // batches below filter_min_batch
-    int filter_min_batch = 16;
+    int64_t filter_min_rows = 1;             // batches >= filter_min_batch: only the tile-count condition applies
+    int64_t filter_min_rows_small = 100000;  // batches below filter_min_batch: filter when rows * B reaches this
+    int filter_min_batch = 9;
     int sample_tiles = 1024;  // upper bound on sampled tiles
     int sample_div = 40;      // sample about 1/40 of the tiles (2.5 % extra GEMM work), see sample_tile_count()
     int hit_cap_q = 8192;
@@ -694,10 +694,12 @@ int exact_scan(codd_knn_index* ix, const float* qn, int nqueries, int k, uint32_
     const int slots = k <= 64 ? 1 : 2;
     const int64_t stride_q = blocks * k;
     if ((rc = ensure_buf(&ix->partial, &ix->partial_cap, (int64_t)nqueries * stride_q)) != 0) return rc;
-    for (int q0 = 0; q0 < nqueries; q0 += 8) {
-        const int nq = nqueries - q0 < 8 ? nqueries - q0 : 8;
-        const int nb = nq == 1 ? 1 : (nq <= 4 ? 4 : 8);
-        ScanArgs a{ix->rows, n, ix->dpad, qn + (int64_t)q0 * ix->dpad, nq, k, row_base, ix->partial + (int64_t)q0 * stride_q, stride_q};
+    {
+        // ONE launch: up to 8 queries ride along per pass over the rows; a larger batch loops over groups
+        // of 8 inside the kernel (small corpora stay L2-resident across the groups, and a batch costs one
+        // launch instead of B/8)
+        const int nb = nqueries == 1 ? 1 : (nqueries <= 4 ? 4 : 8);
+        ScanArgs a{ix->rows, n, ix->dpad, qn, nqueries, k, row_base, ix->partial, stride_q};
         const dim3 grid((unsigned)blocks);
         {
             EvScope ev(ix, EV_SCAN, st);
@@ -908,10 +910,10 @@ bool filter_applies(const codd_knn_index* ix, int B, int k) {
     const int64_t ntiles = (ix->count + kTileRows - 1) / kTileRows;
     const int64_t ts = sample_tile_count(ix, ntiles, k);
     if (!(ix->filter_enabled && ix->all_normalized && ix->shadow) || ts < 2 * (int64_t)k) return false;
-    // large batches: always worth it past a few tiles per CU; small batches (the single-query latency
-    // point): the bf16 stream halves the bytes, which beats the extra launches from ~0.5M rows on
+    // measured on MI355X (scripts/crossover.py, d = 768): with more than 8 queries the filter wins at every size
+    // it is sound for; up to 8 queries the exact scan's single launch wins until rows * B reaches ~100k
     if (B >= ix->filter_min_batch) return ix->count >= ix->filter_min_rows;
-    return ix->count >= ix->filter_min_rows_small;
+    return ix->count * (int64_t)B >= ix->filter_min_rows_small;
 }
 
 // the whole shard-local search: normalise queries, then filter passes or exact scans, keys out.

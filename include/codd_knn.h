@@ -153,8 +153,9 @@ int codd_knn_ivf_search(codd_knn_index* index, const float* dev_queries, int B, 
 /*
  * Tuning / introspection (never needed for correctness).
  *   options: "scan_blocks_per_cu" (1..8); "filter" (0/1: MFMA filter path for large batches);
- *            "filter_min_batch" (16), "filter_min_rows" (32768, batches >= filter_min_batch),
- *            "filter_min_rows_small" (500000, smaller batches): when the filter path is taken;
+ *            "filter_min_batch" (9), "filter_min_rows" (1: batches >= filter_min_batch always
+ *            filter when the corpus has >= 2k sample tiles), "filter_min_rows_small" (100000:
+ *            smaller batches filter when rows * B reaches it): when the filter path is taken;
  *            "sample_div" (40: about 1/40 of the tiles set the per-query thresholds), "sample_tiles"
  *            (1024: upper bound on that number), "hit_cap" (per-query
  *            candidate capacity; overflow falls back to the exact scan);

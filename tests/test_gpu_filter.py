@@ -105,16 +105,24 @@ def test_every_query_block_count_is_exact(Index, B):
     ix.close()
 
 
-def test_small_batches_take_the_exact_scan_on_small_corpora(Index):
+def test_path_selection_follows_the_measured_rule(Index):
+    """<= 8 queries: exact scan until rows * B reaches 100k; more than 8 queries: the filter whenever the
+    corpus has enough tiles for sound thresholds (scripts/crossover.py is where the rule was measured)."""
     rng = np.random.default_rng(4)
     raw = rng.standard_normal((40_000, 128)).astype(np.float32)
     ix = Index(128)
     ix.upsert(np.arange(40_000, dtype=np.int64), raw)
-    ix.search(rng.standard_normal((4, 128)).astype(np.float32), 5)      # B < 16, rows < 500k: scan
+    ix.search(rng.standard_normal((2, 128)).astype(np.float32), 5)      # 80k < 100k: scan
     assert ix.stat("filter_passes") == 0
-    ix.search(rng.standard_normal((16, 128)).astype(np.float32), 5)     # B >= 16, rows >= 32768: filter
+    ix.search(rng.standard_normal((3, 128)).astype(np.float32), 5)      # 120k: filter
     assert ix.stat("filter_passes") == 1
-    ix.close()
+    ix.search(rng.standard_normal((16, 128)).astype(np.float32), 5)     # > 8 queries: filter
+    assert ix.stat("filter_passes") == 2
+    small = Index(128)
+    small.upsert(np.arange(3_000, dtype=np.int64), raw[:3_000])         # 12 tiles < 2k: never sound for k = 10
+    d, r = small.search(rng.standard_normal((64, 128)).astype(np.float32), 10)
+    assert small.stat("filter_passes") == 0 and small.stat("scan_launches") == 1   # one launch for the whole batch
+    ix.close(); small.close()
 
 
 def test_overflow_falls_back_and_stays_exact(Index):
