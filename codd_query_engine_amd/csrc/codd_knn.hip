@@ -426,9 +426,9 @@ static const char* const kEvNames[EV_KINDS] = {"scan", "filter", "sample", "fina
 struct FilterCtl {
     unsigned hit_cnt[kTileQ];
     unsigned flags[FLAG_WORDS];
-    unsigned fb_count;
-    unsigned stats[3];  // hits, survivors, (spare)
-    unsigned fb_list[kTileQ];
+    unsigned fb_count;         // queries queued for the exact-scan fallback ...
+    unsigned pad_[3];
+    unsigned fb_list[kTileQ];  // ... and which ones
 };
 
 struct codd_knn_index {

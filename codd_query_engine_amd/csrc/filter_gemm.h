@@ -127,7 +127,7 @@ constexpr int kPrefetch = CODD_RING - 1;  // K-steps the corpus loads run ahead
 enum { MODE_FILTER = 0, MODE_SAMPLE = 1, MODE_DUMP = 2 };
 
 // flags[] words shared with the host
-enum { FLAG_WG_OVERFLOW = 0, FLAG_NEED_FALLBACK = 1, FLAG_WORDS = 4 };
+enum { FLAG_WG_OVERFLOW = 0 /* statistics: a workgroup hit list filled up */, FLAG_NEED_FALLBACK = 1 /* any query queued */, FLAG_WORDS = 4 };
 
 // 16-byte piece (8 consecutive elements, c8 = element/8) of `row` in the shadow / of query q in qfrag.
 // 32x32x16: lane (h = lane>>5, r = lane&31) of sub-step kk holds k = 64s + 32h + 8kk + 0..7
