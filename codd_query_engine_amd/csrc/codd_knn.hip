@@ -453,7 +453,7 @@ struct codd_knn_index {
     int filter_min_batch = 9;
     int sample_tiles = 1024;  // upper bound on sampled tiles
     int sample_div = 40;      // sample about 1/40 of the tiles (2.5 % extra GEMM work), see sample_tile_count()
-    int hit_cap_q = 8192;
+    int hit_cap_q = 32768;  // candidates kept per query before it falls back to the exact scan (64 MiB at 256 queries)
 
     // workspaces (grown on demand, never inside a captured region after warm-up)
     float* qn = nullptr;       int64_t qn_cap = 0;        // [B][dpad] normalised queries

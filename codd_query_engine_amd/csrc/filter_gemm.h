@@ -398,9 +398,13 @@ __global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_
                                             lds_hits[slot * 3 + 1] = (unsigned)row;
                                             lds_hits[slot * 3 + 2] = (unsigned)(qb * kMB + c);
                                         } else {
-                                            // list full (> kHitCap/2 hits inside ONE tile): this query's candidates
-                                            // are incomplete -> poison its counter (top bit: reads as "> cap" and can
-                                            // never wrap) so that finalize sends exactly this query to the exact scan
+                                            // workgroup list full (> kHitCap/2 hits inside ONE tile: a dense cluster
+                                            // that many queries point at): this query's candidates are incomplete ->
+                                            // poison its counter (top bit: reads as "> cap", can never wrap) so that
+                                            // finalize queues exactly this query for the exact scan.  (Appending to the
+                                            // global list from here instead was measured 5 % slower on the whole kernel:
+                                            // the extra address arithmetic / call in the epilogue hurts the MFMA loop's
+                                            // register allocation.)
                                             atomicOr(&hit_cnt[qb * kMB + c], 0x80000000u);
                                         }
                                     }
@@ -502,10 +506,10 @@ __global__ __launch_bounds__(64) void select_thr_kernel(const float* __restrict_
 //   2. survivors = hits with approx >= a_k - 2*eps  (no other row can reach the exact top-k);
 //   3. exact canonical fp32 score of every survivor (one wave per row, same expression as the scan);
 //   4. top-k of the exact keys -> out_keys[q] (global rows: row_base added).
-// A query whose hit list overflowed (or any workgroup list did) is queued for the exact-scan
+// A query whose global hit list overflowed (more than cap_q candidates) is queued for the exact-scan
 // fallback instead: fb_list[atomicAdd(fb_count)] = q.
 // ---------------------------------------------------------------------------------------------
-constexpr int kSurvivorCap = 2048;
+constexpr int kSurvChunk = 2048;  // hits examined per round; their survivors always fit the LDS list
 
 template <int DT, int NITER, int SLOTS>
 __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ rows_, int dpad, const float* __restrict__ qn,
@@ -517,14 +521,13 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
     typedef RowTraits<DT> RT;
     constexpr int E = RT::E;
     __shared__ u64 lds_list[4 * SLOTS * kWave];
-    __shared__ unsigned lds_surv[kSurvivorCap];
+    __shared__ unsigned lds_surv[kSurvChunk];
     __shared__ unsigned lds_n;
     __shared__ float lds_lo;
 
     const int q = blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned total = hit_cnt[q];
-    const bool overflow = total > (unsigned)cap_q;  // list truncated, or poisoned by a full workgroup list
-    if (overflow) {
+    if (total > (unsigned)cap_q) {  // the candidate list was truncated: only the exact scan can answer this query
         if (tid == 0) {
             fb_list[atomicAdd(fb_count, 1u)] = (unsigned)q;
             atomicOr(&flags[FLAG_NEED_FALLBACK], 1u);
@@ -532,7 +535,6 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
         return;
     }
     const u64* my = hits + (int64_t)q * cap_q;
-    if (tid == 0) lds_n = 0u;
 
     // 1. k-th largest approximate key
     WaveTopK<SLOTS> L;
@@ -557,29 +559,6 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
     __syncthreads();
     const float lo = lds_lo;
 
-    // 2. survivors
-    for (unsigned i = tid; i < total; i += 256) {
-        const u64 key = my[i];
-        if (key_score(key) >= lo) {
-            const unsigned slot = atomicAdd(&lds_n, 1u);
-            if (slot < (unsigned)kSurvivorCap) lds_surv[slot] = key_row(key);
-        }
-    }
-    __syncthreads();
-    const unsigned ns = lds_n;
-    if (ns > (unsigned)kSurvivorCap) {
-        if (tid == 0) {
-            fb_list[atomicAdd(fb_count, 1u)] = (unsigned)q;
-            atomicOr(&flags[FLAG_NEED_FALLBACK], 1u);
-        }
-        return;
-    }
-    if (tid == 0 && stats) {
-        atomicAdd(&stats[0], (unsigned long long)total);
-        atomicAdd(&stats[1], (unsigned long long)ns);
-    }
-
-    // 3. exact canonical scores of the survivors (one wave per row)
     const int nchunks = dpad / E;
     float qf[NITER][E];
 #pragma unroll
@@ -591,25 +570,61 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
     const uint4* base = reinterpret_cast<const uint4*>(rows_);
     WaveTopK<SLOTS> X;
     X.init();
-    for (unsigned j = wave; j < ns; j += 4) {
-        const unsigned row = lds_surv[j];
-        const uint4* p = base + (int64_t)row * nchunks + lane;
-        float acc = 0.0f;
-#pragma unroll
-        for (int it = 0; it < NITER; ++it) {
-            uint4 cch = make_uint4(0u, 0u, 0u, 0u);
-            if (lane + kWave * it < nchunks) cch = p[kWave * it];
-            float w[E];
-            RT::widen(cch, w);
-#pragma unroll
-            for (int e = 0; e < E; ++e) acc = __builtin_fmaf(qf[it][e], w[e], acc);
+    unsigned survivors = 0;
+
+    // 2 + 3. round by round: survivors of the next kSurvChunk hits (approx >= a_k - 2 eps: no other row can reach
+    // the exact top-k) are compacted into LDS and re-scored exactly, four rows per wave step, with the same
+    // canonical expression as the scan.  No cap on the number of survivors: a dense cluster costs time, not exactness.
+    for (unsigned b0 = 0; b0 < total; b0 += kSurvChunk) {
+        if (tid == 0) lds_n = 0u;
+        __syncthreads();
+        const unsigned b1 = b0 + kSurvChunk < total ? b0 + kSurvChunk : total;
+        for (unsigned i = b0 + tid; i < b1; i += 256) {
+            const u64 key = my[i];
+            if (key_score(key) >= lo) lds_surv[atomicAdd(&lds_n, 1u)] = key_row(key);
         }
-        const float s = butterfly_sum(acc);
-        X.offer(make_key(s, row_base + row), k, lane);
+        __syncthreads();
+        const unsigned ns = lds_n;
+        survivors += ns;
+        for (unsigned j = wave * 4; j < ns; j += 16) {
+            float w[4][NITER][E];
+            unsigned rowid[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                rowid[r] = lds_surv[j + r < ns ? j + r : ns - 1];
+                const uint4* p = base + (int64_t)rowid[r] * nchunks + lane;
+#pragma unroll
+                for (int it = 0; it < NITER; ++it) {
+                    uint4 cch = make_uint4(0u, 0u, 0u, 0u);
+                    if (lane + kWave * it < nchunks) cch = p[kWave * it];
+                    RT::widen(cch, w[r][it]);
+                }
+            }
+            float a[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int it = 0; it < NITER; ++it)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc = __builtin_fmaf(qf[it][e], w[r][it][e], acc);
+                a[r] = acc;
+            }
+            const float y = butterfly_sum4(a[0], a[1], a[2], a[3], lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(y), 16 * r));
+                if (j + r < ns) X.offer(make_key(sc, row_base + rowid[r]), k, lane);
+            }
+        }
+        __syncthreads();  // lds_surv is refilled by the next round
+    }
+    if (tid == 0 && stats) {
+        atomicAdd(&stats[0], (unsigned long long)total);
+        atomicAdd(&stats[1], (unsigned long long)survivors);
     }
 
     // 4. merge the four wave lists
-    __syncthreads();
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) lds_list[(wave * SLOTS + s) * kWave + lane] = X.v[s];
     __syncthreads();

@@ -166,6 +166,47 @@ def test_workgroup_hit_list_overflow_poisons_only_the_affected_queries(Index):
     ix.close()
 
 
+def test_dense_cluster_costs_time_not_exactness(Index):
+    """3,000 rows within a hair of each other and of the query: all of them survive the 2-eps band, more than
+    one finalize round (2,048 hits) can hold; the rounds stream through them, no cap, no fallback."""
+    rng = np.random.default_rng(16)
+    n, d, k = 30_000, 256, 10
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    centre = rng.standard_normal(d).astype(np.float32)
+    members = rng.choice(n, size=3000, replace=False)
+    raw[members] = centre + 2e-3 * rng.standard_normal((3000, d)).astype(np.float32)
+    q = rng.standard_normal((10, d)).astype(np.float32)
+    q[0] = centre
+    ix = build(Index, raw)
+    dist, rows = ix.search(q, k)
+    d_ref, i_ref = oracle_answer(raw, q, k, "f32")
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    assert ix.stat("fallback_queries") == 0 and ix.stat("filter_survivors") >= 3000
+    ix.close()
+
+
+def test_zero_query_and_zero_rows_through_the_filter(Index):
+    """A zero query scores 0 against everything: every row is a candidate and a survivor (20,000 of them, streamed
+    through finalize in rounds) and the answer is rows 0..k-1 at distance exactly 1; zero rows score 0 and never
+    beat real neighbours."""
+    rng = np.random.default_rng(12)
+    n, d, k = 20_000, 256, 10
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    raw[100:110] = 0.0
+    q = rng.standard_normal((12, d)).astype(np.float32)
+    q[5] = 0.0
+    ix = build(Index, raw)
+    dist, rows = ix.search(q, k)
+    d_ref, i_ref = oracle_answer(raw, q, k, "f32")
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    assert rows[5].tolist() == list(range(k)) and (dist[5] == 1.0).all()
+    assert ix.stat("filter_survivors") >= n
+    ix.set_option("hit_cap", 4096)      # now the zero query's 20,000 candidates overflow: exact-scan fallback, same bits
+    dist2, rows2 = ix.search(q, k)
+    assert np.array_equal(rows2, i_ref) and np.array_equal(dist2, d_ref) and ix.stat("fallback_queries") >= 1
+    ix.close()
+
+
 def test_ties_resolve_to_lower_row_through_the_filter(Index):
     rng = np.random.default_rng(2)
     n, d = 35_000, 768

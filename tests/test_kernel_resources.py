@@ -1,0 +1,30 @@
+"""Compile-time guard for the hot kernels (no GPU needed: hipcc cross-compiles for gfx950).
+
+The MFMA filter GEMM lives at the edge of the 256-VGPR budget (2 waves per SIMD) and its K-loop must be fully
+unrolled by the register-ring depth — if either slips (a spill to scratch, or the ring indexed at run time) the
+kernel still computes the right answer, only several times slower.  This test reads hipcc's own resource report."""
+
+import re
+import subprocess
+
+from codd_query_engine_amd import build as b
+
+
+def test_hot_kernels_do_not_spill():
+    cmd = [b._hipcc(), *[f for f in b.HIPCC_FLAGS if f != "-shared"], "-c", "-I", b.os.path.join(b._ROOT, "include"), "-I", b.CSRC,
+           "-Rpass-analysis=kernel-resource-usage", "-o", "/dev/null", b.os.path.join(b.CSRC, b.SOURCES[0])]
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    report = b.resource_report(proc.stderr)
+    rows = {}
+    for line in report.splitlines()[1:]:
+        m = re.match(r"(.+?)\s+(\d+)\s+(\S+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)$", line)
+        if m:
+            rows[m.group(1).strip()] = {"vgpr": int(m.group(2)), "spill": int(m.group(4)), "scratch": int(m.group(5)), "occ": int(m.group(6))}
+    hot = [name for name in rows if "gemm_filter_kernel" in name or "scan_topk_kernel<0, 1, 3" in name or "scan_topk_kernel<0, 8, 3" in name
+           or "finalize_kernel<0, 3" in name]
+    assert len(hot) >= 12, report
+    for name in hot:
+        assert rows[name]["scratch"] == 0 and rows[name]["spill"] == 0, f"{name} spills:\n{report}"
+    full = next(name for name in rows if "gemm_filter_kernel<0, 8>" in name)
+    assert rows[full]["vgpr"] <= 256 and rows[full]["occ"] == 2, report
