@@ -451,7 +451,7 @@ struct codd_knn_index {
     int64_t filter_min_rows = 1;             // batches >= filter_min_batch: only the tile-count condition applies
     int64_t filter_min_rows_small = 100000;  // batches below filter_min_batch: filter when rows * B reaches this
     int filter_min_batch = 9;
-    int sample_tiles = 1024;  // upper bound on sampled tiles
+    int sample_tiles = 4096;  // upper bound on sampled tiles (reached from 42M rows on)
     int sample_div = 40;      // sample about 1/40 of the tiles (2.5 % extra GEMM work), see sample_tile_count()
     int hit_cap_q = 32768;  // candidates kept per query before it falls back to the exact scan (64 MiB at 256 queries)
 

@@ -255,6 +255,39 @@ def test_too_few_tiles_for_k_takes_the_exact_scan(Index):
     ix.close()
 
 
+def test_full_baseline_size_properties(Index):
+    """BASELINE configs[2] at full size (10M x 768 fp32, B = 256, k = 10), through size-independent properties:
+    planted near-duplicates come back in planted order; distances ascend; the filter leg and the exact scan
+    return the same bits for a slice of the batch; one query (B = 1 path) equals its row of the batch."""
+    import torch
+
+    n, d, B, k = 10_000_000, 768, 256, 10
+    ix = Index(d)
+    ix.reserve(n)
+    for c in range(n // 250_000):
+        g = torch.Generator(device="cuda").manual_seed(1234 + c)
+        ix.upsert_device(c * 250_000, torch.randn((250_000, d), generator=g, device="cuda"))
+    q = torch.randn((B, d), generator=torch.Generator(device="cuda").manual_seed(4321), device="cuda")
+    gp = torch.Generator(device="cuda").manual_seed(99)
+    planted = []
+    for b in range(3):
+        for j in range(k):
+            row = (b * 1_234_567 + j * 99_991 + 17) % n
+            noise = torch.randn(d, generator=gp, device="cuda")
+            ix.upsert_device(row, (q[b] + 0.02 * (j + 1) * noise * q[b].norm() / noise.norm())[None, :].contiguous())
+            planted.append(row)
+    dist, rows = ix.search_tensors(q, k)
+    assert rows[:3].cpu().numpy().tolist() == np.array(planted).reshape(3, k).tolist()
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all()) and bool((rows >= 0).all())
+    assert ix.stat("filter_passes") == 1 and ix.stat("fallback_queries") == 0
+    d1, r1 = ix.search_tensors(q[7:8], k)                      # single-query path (NBQ = 1 instantiation)
+    assert torch.equal(r1[0], rows[7]) and torch.equal(d1[0], dist[7])
+    ix.set_option("filter", 0)
+    de, re_ = ix.search_tensors(q[:8], k)                      # exact scan, one pass over 30.7 GB
+    assert torch.equal(re_, rows[:8]) and torch.equal(de, dist[:8])
+    ix.close()
+
+
 def test_unnormalised_rows_disable_the_filter(Index):
     rng = np.random.default_rng(3)
     raw = rng.standard_normal((40_000, 128)).astype(np.float32)
