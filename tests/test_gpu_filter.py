@@ -72,6 +72,9 @@ def test_mfma_scores_match_rounded_operand_reference(Index, n, d, B, dtype):
         (40_000, 768, 96, 10, "bf16"),
         (12_000, 1024, 48, 10, "f16"),
         (5_200, 128, 20, 10, "f32"),     # 21 tiles: barely enough buckets for k = 10
+        (30_000, 64, 40, 10, "f32"),     # ONE K-step per tile (query stages wrap inside a stage)
+        (30_000, 320, 40, 10, "f32"),    # odd number of K-steps (5): tiles end mid-stage
+        (8_000, 2048, 24, 10, "bf16"),   # widest row (32 K-steps)
     ],
 )
 def test_filter_path_is_exact(Index, n, d, B, k, dtype):
