@@ -820,9 +820,9 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     int rc;
     ix->stat_filter_passes++;
 
-    hipLaunchKernelGGL(qfrag_kernel, dim3((kTileQ * (ix->dpad / 8) + 255) / 256), dim3(256), 0, st, qn, nq, ix->dpad, ix->qfrag);
+    hipLaunchKernelGGL(qfrag_kernel, dim3((kTileQ * (ix->dpad / 8) + 255) / 256), dim3(256), 0, st, qn, nq, ix->dpad, ix->qfrag,
+                       reinterpret_cast<unsigned*>(ix->ctl), (int)(sizeof(FilterCtl) / 4));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemsetAsync(ix->ctl, 0, sizeof(FilterCtl), st));
 
     // sample: every `stride`-th tile
     const int64_t ts = sample_tile_count(ix, ntiles, k);
@@ -1161,7 +1161,8 @@ int codd_knn_approx_scores(codd_knn_index* ix, const float* dev_queries, int B, 
     if ((rc = ensure_buf(&ix->qn, &ix->qn_cap, (int64_t)B * ix->dpad)) != 0) return rc;
     if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
     if ((rc = launch_normalize(DT_F32, dev_queries, B, ix->dim, ix->dpad, 1, nullptr, 0, ix->qn, nullptr, st)) != 0) return rc;
-    hipLaunchKernelGGL(qfrag_kernel, dim3((kTileQ * (ix->dpad / 8) + 255) / 256), dim3(256), 0, st, ix->qn, B, ix->dpad, ix->qfrag);
+    hipLaunchKernelGGL(qfrag_kernel, dim3((kTileQ * (ix->dpad / 8) + 255) / 256), dim3(256), 0, st, ix->qn, B, ix->dpad, ix->qfrag,
+                       (unsigned*)nullptr, 0);
     const int64_t ntiles = (ix->count + kTileRows - 1) / kTileRows;
     const int64_t g = ntiles < ix->num_cus ? ntiles : ix->num_cus;
     hipLaunchKernelGGL((gemm_filter_kernel<MODE_DUMP, 8>), dim3((unsigned)g), dim3(kFilterThreads), filter_lds_bytes(MODE_DUMP), st, ix->shadow,

@@ -168,9 +168,12 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 
 // qn: [B][dpad] fp32 normalised queries -> qfrag pieces (queries >= B are zero).  One thread per piece.
-__global__ __launch_bounds__(256) void qfrag_kernel(const float* __restrict__ qn, int B, int dpad, uint4* __restrict__ qfrag) {
+// Also zeroes the pass's control block (ctl_words dwords) so that no separate memset launch is needed.
+__global__ __launch_bounds__(256) void qfrag_kernel(const float* __restrict__ qn, int B, int dpad, uint4* __restrict__ qfrag,
+                                                    unsigned* __restrict__ ctl, int ctl_words) {
     const int npieces = kTileQ * (dpad >> 3);
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < ctl_words) ctl[idx] = 0u;
     if (idx >= npieces) return;
     const int q = idx / (dpad >> 3), c8 = idx % (dpad >> 3);
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -197,7 +200,7 @@ __device__ __forceinline__ void flush_hits(const unsigned* lds_hits, unsigned m,
 // gemm_filter_kernel<MODE, NBQ>   (NBQ = 32-query blocks actually multiplied: 1, 2, 4 or 8; a small
 //   batch pays only for its own MFMAs and LDS traffic and the kernel turns into a pure HBM stream)
 //   MODE_FILTER: every (query, row) with approx score >= thr[query] is appended to hits[query][]
-//   MODE_SAMPLE: per (tile, query) the maximum approx score is written to bucket_max[tile][query]
+//   MODE_SAMPLE: per (tile, query) the maximum approx score is written to bucket_max[query][tile]
 //   MODE_DUMP  : all scores to dump[query][row] (diagnostics / layout tests, small n only)
 // Run-tile u (0 <= u < ntiles_run) is corpus tile u*tile_stride; workgroup b takes u = b, b+G, ...
 // ---------------------------------------------------------------------------------------------
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_
                 // all 8 waves have folded this tile into lds_w: publish, reset, and fence the reset
                 // against the next tile's fold
                 if (tid < 256) {
-                    bucket_max[c_u * 256 + tid] = unord_f32(lds_w[tid]);
+                    bucket_max[(int64_t)tid * ntiles_run + c_u] = unord_f32(lds_w[tid]);  // [query][bucket]: select_thr reads rows
                     lds_w[tid] = 0u;
                 }
                 __syncthreads();
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(64) void select_thr_kernel(const float* __restrict_
     L.init();
     for (int64_t i0 = 0; i0 < nbuckets; i0 += kWave) {
         const int64_t i = i0 + lane;
-        const u64 cand = i < nbuckets ? make_key(bucket_max[i * 256 + q], (uint32_t)i) : 0ull;
+        const u64 cand = i < nbuckets ? make_key(bucket_max[(int64_t)q * nbuckets + i], (uint32_t)i) : 0ull;
         L.offer_lanes(cand, k, lane);
     }
     if (lane == 0) thr[q] = L.thr ? key_score(L.thr) - slack : -INFINITY;
