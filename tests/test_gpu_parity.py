@@ -186,17 +186,27 @@ def test_planted_neighbours_at_scale(Index, torch):
 
 
 def test_facade_and_store_run_on_the_hip_engine():
-    from codd_query_engine_amd import KnnClient, MetricsSemanticMetadataStore
+    """BASELINE configs[0] (plumbing): 1,000 synthetic metric records, 384-d embeddings, 20 text queries through
+    store -> façade -> C ABI; every result list must equal the checker engine's (same ids, same fp32 distances)."""
+    from codd_query_engine_amd import KnnClient, MetricsSearchClient, MetricsSemanticMetadataStore
     from tests._oracle_engine import OracleEngine
 
     gpu = MetricsSemanticMetadataStore(KnnClient(device="cuda:0"))
     cpu = MetricsSemanticMetadataStore(KnnClient(engine_factory=lambda dim: OracleEngine(dim)))
-    words = ["cpu", "memory", "disk", "network", "latency", "errors", "requests", "queue", "cache", "gc", "threads", "io"]
+    words = ["cpu", "memory", "disk", "network", "latency", "errors", "requests", "queue", "cache", "gc", "threads", "io",
+             "http", "database", "kafka", "consumer", "lag", "saturation", "bytes", "seconds", "total", "ratio"]
     rng = np.random.default_rng(0)
-    for i in range(300):
-        w = rng.choice(words, size=4, replace=False)
-        md = {"metric_name": f"svc.m{i}", "description": " ".join(w) + f" metric {i}", "category": w[0], "golden_signal_type": w[1]}
-        gpu.index_metadata("ns", md)
-        cpu.index_metadata("ns", md)
-    for query in ["cpu latency", "disk io errors", "cache memory threads", "requests queue"]:
-        assert gpu.search_metadata(query, n_results=20) == cpu.search_metadata(query, n_results=20)
+    records = []
+    for i in range(1000):
+        w = rng.choice(words, size=5, replace=False)
+        records.append({"metric_name": f"svc.{w[0]}.{w[1]}.m{i}", "description": " ".join(w) + f" metric number {i}", "category": w[0],
+                        "subcategory": w[2], "golden_signal_type": w[3], "meter_type": "gauge"})
+    for chunk in range(0, 1000, 250):  # the batched ingest extension: 4 upserts instead of 1000
+        assert gpu.index_metadata_batch("ns", records[chunk : chunk + 250]) == cpu.index_metadata_batch("ns", records[chunk : chunk + 250])
+    assert gpu.collection.count() == 1000
+    queries = [" ".join(rng.choice(words, size=int(rng.integers(1, 4)), replace=False)) for _ in range(20)]
+    for query in queries:
+        assert gpu.search_metadata(query, n_results=10) == cpu.search_metadata(query, n_results=10)
+    assert gpu.search_metadata_batch(queries, n_results=10) == cpu.search_metadata_batch(queries, n_results=10)
+    top = MetricsSearchClient(gpu).search_relevant_metrics("kafka consumer lag", limit=5)
+    assert len(top) == 5 and all("kafka" in r["description"] or "consumer" in r["description"] or "lag" in r["description"] for r in top[:1])
