@@ -49,8 +49,13 @@ constexpr int kStagePieces = 2048;  // 16-byte pieces of one query K-slice (256 
 #ifndef CODD_RB
 #define CODD_RB 1            // 32-row corpus blocks per wave: 1 -> 8 waves x 256 regs, 2 -> 4 waves x 512 regs
 #endif
+#ifndef CODD_QSPLIT
+#define CODD_QSPLIT 1        // 2: two waves share each row group and take half of the query blocks each
+#endif
 constexpr int kRB = CODD_RB;
-constexpr int kFilterWaves = 8 / kRB;
+constexpr int kQSplit = CODD_QSPLIT;
+constexpr int kRowGroups = 8 / kRB;                   // row groups of a 256-row tile
+constexpr int kFilterWaves = kRowGroups * kQSplit;
 constexpr int kFilterThreads = 64 * kFilterWaves;
 constexpr int kQP = kStagePieces / kFilterThreads;  // query-slice pieces each thread stages per K-step
 #ifndef CODD_MFMA16
@@ -64,7 +69,7 @@ constexpr int kAccRegs = CODD_MFMA16 ? 4 : 16;
 constexpr int kKS = CODD_MFMA16 ? 2 : 4;           // MFMA K sub-steps per 64-wide K-step
 constexpr int kRS = (32 / kMB) * kRB;              // row blocks per wave
 constexpr int kQBper32 = 32 / kMB;                 // query blocks per 32 queries
-static_assert(!(CODD_MFMA16 && CODD_RB != 1), "the 16x16x32 shape is only built with one 32-row block per wave");
+static_assert(kFilterWaves <= 8, "at most 8 waves per workgroup");
 #if CODD_MFMA16
 typedef __attribute__((ext_vector_type(4))) float acc_t;
 #else
@@ -205,7 +210,7 @@ __device__ __forceinline__ void flush_hits(const unsigned* lds_hits, unsigned m,
 // Run-tile u (0 <= u < ntiles_run) is corpus tile u*tile_stride; workgroup b takes u = b, b+G, ...
 // ---------------------------------------------------------------------------------------------
 template <int MODE, int NBQ>
-__global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_kernel(
+__global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gemm_filter_kernel(
     const uint4* __restrict__ shadow, const uint4* __restrict__ qfrag, int64_t n, int nsteps, int64_t ntiles_run,
     int64_t tile_stride, const float* __restrict__ thr, float* __restrict__ bucket_max, u64* __restrict__ hits,
     unsigned* __restrict__ hit_cnt, int cap_q, unsigned* __restrict__ flags, float* __restrict__ dump) {
@@ -215,7 +220,11 @@ __global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_
     unsigned* lds_hits = lds_w + 320;                                    // kHitCap x 3 dwords (FILTER only)
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = lane & (kMB - 1);  // query inside an MFMA query block
+    const int wr = kQSplit == 1 ? wave : wave % kRowGroups;  // row group of the tile this wave owns
+    const int qh = kQSplit == 1 ? 0 : wave / kRowGroups;     // which share of the query blocks
+    const int c = lane & (kMB - 1);    // query inside an MFMA query block
+    const int qoff = qh * b_piece(NBQ * kQBper32 / kQSplit, 0) * 64;  // first LDS piece of this wave's query blocks
+    const int qbase = qh * (NBQ * kQBper32 / kQSplit) * kMB + c;     // this lane's query in query block 0 of the wave
 
     const int64_t G = gridDim.x;
     const int64_t my_tiles = ntiles_run > (int64_t)blockIdx.x ? (ntiles_run - blockIdx.x + G - 1) / G : 0;
@@ -231,7 +240,9 @@ __global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_
 
     constexpr int kSP = NBQ * 256;  // 16-byte pieces of a query slice that are actually staged
     constexpr int kQPn = kSP / kFilterThreads > 0 ? kSP / kFilterThreads : 1;
-    constexpr int NQB = NBQ * kQBper32;  // MFMA query blocks
+    constexpr int NQBall = NBQ * kQBper32;       // MFMA query blocks of the pass
+    constexpr int NQB = NQBall / kQSplit;        // ... of this wave
+    static_assert(NQBall % kQSplit == 0, "query blocks must split evenly");
     acc_t acc[kRS][NQB];
 #pragma unroll
     for (int rs = 0; rs < kRS; ++rs)
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_
     auto load_a = [&](uint4(&dst)[kRB][4]) {
 #pragma unroll
         for (int rb = 0; rb < kRB; ++rb) {
-            const int64_t block = (CODD_EXP_SAME_TILE ? 0 : l_u * tile_stride * 8) + wave * kRB + rb;
+            const int64_t block = (CODD_EXP_SAME_TILE ? 0 : l_u * tile_stride * 8) + wr * kRB + rb;
             const uint4* p = shadow + ((block * nsteps + l_s) * 4) * 64 + lane;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -322,11 +333,11 @@ __global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_
             // corpus fragments for step t+2 AFTER the query loads: vmcnt retires in order, so the
             // end-of-step wait for the (L2-served) query slice must not sit behind these HBM loads
             load_a(ring[(i + kPrefetch) % kRing]);
-            const uint4* qs = ldsQ + ((stage & 1) * kQS + sub) * kStagePieces + lane;
+            const uint4* qs = ldsQ + ((stage & 1) * kQS + sub) * kStagePieces + lane + qoff;  // qoff: this wave's query share
 #if CODD_MFMA_PRIO
             __builtin_amdgcn_s_setprio(1);
 #endif
-            constexpr int kNqbRun = (CODD_EXP_NB < NBQ ? CODD_EXP_NB : NBQ) * kQBper32;
+            constexpr int kNqbRun = (CODD_EXP_NB < NBQ ? CODD_EXP_NB : NBQ) * kQBper32 / kQSplit;
 #pragma unroll
             for (int ks = 0; ks < kKS; ++ks) {
 #pragma unroll
@@ -381,11 +392,11 @@ __global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_
                 const bool ragged = (tile + 1) * kTileRows > n;
 #pragma unroll
                 for (int rs = 0; rs < kRS; ++rs) {
-                    const int64_t row0 = tile * kTileRows + wave * (32 * kRB) + rs * kMB;  // + acc_row(r, lane)
+                    const int64_t row0 = tile * kTileRows + wr * (32 * kRB) + rs * kMB;  // + acc_row(r, lane)
                     if (MODE == MODE_FILTER) {
 #pragma unroll
                         for (int qb = 0; qb < NQB; ++qb) {
-                            const float th = CODD_EXP_NO_HITS ? INFINITY : __uint_as_float(lds_w[qb * kMB + c]);
+                            const float th = CODD_EXP_NO_HITS ? INFINITY : __uint_as_float(lds_w[qbase + qb * kMB]);
                             float m = acc[rs][qb][0];
 #pragma unroll
                             for (int r = 1; r < kAccRegs; ++r) m = fmaxf(m, acc[rs][qb][r]);
@@ -399,7 +410,7 @@ __global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_
                                         if (slot < (unsigned)kHitCap) {
                                             lds_hits[slot * 3 + 0] = __float_as_uint(v);
                                             lds_hits[slot * 3 + 1] = (unsigned)row;
-                                            lds_hits[slot * 3 + 2] = (unsigned)(qb * kMB + c);
+                                            lds_hits[slot * 3 + 2] = (unsigned)(qbase + qb * kMB);
                                         } else {
                                             // workgroup list full (> kHitCap/2 hits inside ONE tile: a dense cluster
                                             // that many queries point at): this query's candidates are incomplete ->
@@ -408,7 +419,7 @@ __global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_
                                             // global list from here instead was measured 5 % slower on the whole kernel:
                                             // the extra address arithmetic / call in the epilogue hurts the MFMA loop's
                                             // register allocation.)
-                                            atomicOr(&hit_cnt[qb * kMB + c], 0x80000000u);
+                                            atomicOr(&hit_cnt[qbase + qb * kMB], 0x80000000u);
                                         }
                                     }
                                 }
@@ -424,7 +435,7 @@ __global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_
                                 const float v = (!ragged || row < n) ? acc[rs][qb][r] : -INFINITY;
                                 m = fmaxf(m, v);
                             }
-                            atomicMax(&lds_w[qb * kMB + c], ord_f32(m));
+                            atomicMax(&lds_w[qbase + qb * kMB], ord_f32(m));
                         }
                     } else {
 #pragma unroll
@@ -432,7 +443,7 @@ __global__ __launch_bounds__(kFilterThreads, kRB == 1 ? 2 : 1) void gemm_filter_
 #pragma unroll
                             for (int r = 0; r < kAccRegs; ++r) {
                                 const int64_t row = row0 + acc_row(r, lane);
-                                if (row < n) dump[(int64_t)(qb * kMB + c) * n + row] = acc[rs][qb][r];
+                                if (row < n) dump[(int64_t)(qbase + qb * kMB) * n + row] = acc[rs][qb][r];
                             }
                     }
                 }  // rs

@@ -18,11 +18,8 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "base": {},
-    "qs1": {"CODD_QS": 1},
+    "qsplit": {"CODD_RB": 2, "CODD_QSPLIT": 2, "CODD_RING": 2},
     "ring2": {"CODD_RING": 2},
-    "mfma32": {"CODD_MFMA16": 0},
-    "f16shadow": {"CODD_SHADOW_F16": 1},
-    "nont": {"CODD_NT_LOADS": 0},
 }
 
 
