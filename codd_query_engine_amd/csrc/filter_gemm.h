@@ -99,6 +99,9 @@ __device__ __forceinline__ int acc_row(int r, int lane) {
 #ifndef CODD_NT_LOADS
 #define CODD_NT_LOADS 1      // corpus fragments with the non-temporal cache policy (read-once stream)
 #endif
+#ifndef CODD_BLOCKED_TILES
+#define CODD_BLOCKED_TILES 0 // 1: workgroup b walks a contiguous range of tiles instead of b, b+G, b+2G, ...
+#endif
 #ifndef CODD_NO_EPILOGUE
 #define CODD_NO_EPILOGUE 0   // diagnostic only: skip the threshold test (results are wrong)
 #endif
@@ -227,7 +230,14 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
     const int qbase = qh * (NBQ * kQBper32 / kQSplit) * kMB + c;     // this lane's query in query block 0 of the wave
 
     const int64_t G = gridDim.x;
+#if CODD_BLOCKED_TILES
+    const int64_t per_wg = (ntiles_run + G - 1) / G;
+    const int64_t first_u = (int64_t)blockIdx.x * per_wg, step_u = 1;
+    const int64_t my_tiles = first_u >= ntiles_run ? 0 : (first_u + per_wg <= ntiles_run ? per_wg : ntiles_run - first_u);
+#else
+    const int64_t first_u = blockIdx.x, step_u = G;
     const int64_t my_tiles = ntiles_run > (int64_t)blockIdx.x ? (ntiles_run - blockIdx.x + G - 1) / G : 0;
+#endif
     const int T = (int)(my_tiles * nsteps);  // K-steps of this workgroup (< 2^30: rows < 2^32, nsteps <= 64)
     if (T == 0) return;
 
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
             for (int i = 0; i < kAccRegs; ++i) acc[rs][qb][i] = 0.0f;
 
     // load cursor (runs kPrefetch steps ahead of the compute cursor)
-    int64_t l_u = blockIdx.x;  // run-tile ordinal
+    int64_t l_u = first_u;  // run-tile ordinal
     int l_s = 0;
     // always issues its 4 loads (a conditional load would make hipcc's vmcnt bookkeeping assume the
     // worst at every join): past the last step the cursor simply stays on the last valid slice
@@ -274,7 +284,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
             }
         }
         if (--l_left > 0) {
-            if (++l_s == nsteps) { l_s = 0; l_u += G; }
+            if (++l_s == nsteps) { l_s = 0; l_u += step_u; }
         }
     };
 
@@ -309,7 +319,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
     // for its whole cluster while the other loads/stages, which staggers them by half a step
     if (__builtin_amdgcn_readfirstlane(tid) >= kFilterThreads / 2) __builtin_amdgcn_s_setprio(CODD_STATIC_PRIO);
 #endif
-    int64_t c_u = blockIdx.x;  // compute cursor
+    int64_t c_u = first_u;  // compute cursor
     int c_s = 0;
     // T is walked in whole rings: the (at most kRing-1) padding steps past T recompute the last slice
     // into accumulators nobody reads (`live` gates every side effect), which keeps the loop free of
@@ -479,7 +489,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                 }
                 __syncthreads();
             }
-            if (++c_s == nsteps) { c_s = 0; c_u += G; }
+            if (++c_s == nsteps) { c_s = 0; c_u += step_u; }
         }
     }
 

@@ -18,8 +18,7 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "base": {},
-    "qsplit": {"CODD_RB": 2, "CODD_QSPLIT": 2, "CODD_RING": 2},
-    "ring2": {"CODD_RING": 2},
+    "blocked": {"CODD_BLOCKED_TILES": 1},
 }
 
 
