@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Randomised soak: the MFMA filter leg against the exact scan (both on the GPU), bit for bit, over random
+shapes, dtypes, k and data kinds for a wall-clock budget.  Development tool; prints one line per failure."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from codd_query_engine_amd.knn_index import DeviceKnnIndex
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t_end, cases, fails, fallbacks = time.time() + budget, 0, 0, 0
+while time.time() < t_end:
+    d = int(rng.choice([64, 128, 192, 256, 320, 384, 512, 768, 1024]))
+    dtype = str(rng.choice(["f32", "bf16", "f16"]))
+    n = int(rng.integers(6_000, 250_000))
+    B = int(rng.choice([1, 2, 7, 8, 9, 31, 32, 33, 64, 100, 128, 129, 255, 256, 257, 300]))
+    k = int(rng.choice([1, 5, 10, 10, 10, 33, 64, 65, 100]))
+    kind = str(rng.choice(["random", "clustered", "dupes"]))
+    g = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
+    x = torch.randn((n, d), generator=g, device="cuda")
+    if kind == "clustered":
+        c = torch.randn((int(rng.integers(4, 200)), d), generator=g, device="cuda")
+        x = c[torch.randint(0, c.shape[0], (n,), generator=g, device="cuda")] + float(rng.choice([0.05, 0.3, 1.0])) * x
+    elif kind == "dupes":
+        x[torch.randint(0, n, (n // 3,), generator=g, device="cuda")] = x[int(rng.integers(n))].clone()
+    q = torch.randn((B, d), generator=g, device="cuda")
+    if kind != "random":
+        q[: B // 2] = x[torch.randint(0, n, (B // 2,), generator=g, device="cuda")] + 0.01 * q[: B // 2]
+    ix = DeviceKnnIndex(d, dtype)
+    ix.upsert_device(0, x.contiguous())
+    for key in ("filter_min_rows", "filter_min_rows_small", "filter_min_batch"):
+        ix.set_option(key, 1)
+    df, rf = ix.search_tensors(q, k)
+    used_filter = ix.stat("filter_passes") > 0
+    fallbacks += ix.stat("fallback_queries")
+    ix.set_option("filter", 0)
+    de, re_ = ix.search_tensors(q, k)
+    ok = bool(torch.equal(rf, re_) and torch.equal(df, de))
+    cases += 1
+    if not ok:
+        fails += 1
+        bad = (rf != re_).any(dim=1).nonzero().flatten().tolist()[:5]
+        print(f"MISMATCH n={n} d={d} dtype={dtype} B={B} k={k} kind={kind} filter={used_filter} queries={bad}", flush=True)
+    ix.close()
+print(f"soak: {cases} cases, {fails} mismatches, {fallbacks} fallback queries in {budget:.0f} s")
+sys.exit(1 if fails else 0)
