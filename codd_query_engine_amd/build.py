@@ -32,6 +32,11 @@ HIPCC_FLAGS = [
     # exact sequence of fp32 operations shared with oracle/knn_oracle.c
     "-fhip-fp32-correctly-rounded-divide-sqrt",
     "-ffp-contract=off",
+    # the filter GEMM's K loop must unroll over its whole register ring (3 slots x the stage length); if the body
+    # outgrows LLVM's default pragma-unroll budget the ring silently becomes a scratch array
+    # (tests/test_kernel_resources.py guards the outcome)
+    "-mllvm",
+    "-pragma-unroll-threshold=65536",
     "-Wall",
     "-Wno-unused-function",
 ]

@@ -424,7 +424,7 @@ static const char* const kEvNames[EV_KINDS] = {"scan", "filter", "sample", "fina
 
 // device control block of one filter pass (zeroed by ONE memset per pass)
 struct FilterCtl {
-    unsigned hit_cnt[kTileQ];
+    unsigned hit_cnt[kTileQ * kHitCntStride];
     unsigned flags[FLAG_WORDS];
     unsigned fb_count;         // queries queued for the exact-scan fallback ...
     unsigned pad_[3];
@@ -805,6 +805,9 @@ int64_t sample_tile_count(const codd_knn_index* ix, int64_t ntiles, int k) {
     int64_t ts = ntiles / ix->sample_div;
     const int64_t lo = 4 * (int64_t)k > 64 ? 4 * (int64_t)k : 64;
     if (ts < lo) ts = lo;
+    // a sample of fewer tiles than there are CUs takes as long as one full round of workgroups (one tile each), and a
+    // bigger sample means a tighter threshold: fewer hits for the filter's epilogue (scripts/rows_sweep.py)
+    if (ts < ix->num_cus && ntiles >= 2 * (int64_t)ix->num_cus) ts = ix->num_cus;
     if (ts > ix->sample_tiles) ts = ix->sample_tiles;
     if (ts > ntiles) ts = ntiles;
     return ts < 1 ? 1 : ts;

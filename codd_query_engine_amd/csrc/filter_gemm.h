@@ -120,12 +120,22 @@ __device__ __forceinline__ int acc_row(int r, int lane) {
 #ifndef CODD_EXP_NO_LDSREAD
 #define CODD_EXP_NO_LDSREAD 0 // diagnostic only: the query fragment is taken from a register, not from LDS
 #endif
+#ifndef CODD_EXP_NO_FLUSH
+#define CODD_EXP_NO_FLUSH 0  // diagnostic only: the final hit list is dropped (results are wrong)
+#endif
 #ifndef CODD_EXP_NO_BARRIER
 #define CODD_EXP_NO_BARRIER 0 // diagnostic only: no stage barriers (racy)
 #endif
 constexpr int kQS = CODD_QS;
 constexpr int kLdsQBytes = 2 * kQS * kStagePieces * 16;
 constexpr int kHitCap = kQS == 1 ? 4096 : 2048;  // per-workgroup LDS hit list (entries of 3 dwords)
+#ifndef CODD_HITCNT_STRIDE
+#define CODD_HITCNT_STRIDE 1  // dwords between two queries' global hit counters (32 = one 128-byte line each)
+#endif
+#ifndef CODD_FLUSH_AT
+#define CODD_FLUSH_AT (kHitCap / 2)  // a workgroup empties its LDS hit list at the first tile end with more entries
+#endif
+constexpr int kHitCntStride = CODD_HITCNT_STRIDE;
 #ifndef CODD_RING
 #define CODD_RING 3
 #endif
@@ -199,8 +209,47 @@ __device__ __forceinline__ void flush_hits(const unsigned* lds_hits, unsigned m,
     for (unsigned e = tid; e < m; e += kFilterThreads) {
         const float v = __uint_as_float(lds_hits[e * 3 + 0]);
         const unsigned row = lds_hits[e * 3 + 1], q = lds_hits[e * 3 + 2];
-        const unsigned slot = atomicAdd(&hit_cnt[q], 1u);
+        const unsigned slot = atomicAdd(&hit_cnt[q * kHitCntStride], 1u);
         if (slot < (unsigned)cap_q) hits[(int64_t)q * cap_q + slot] = make_key(v, row);
+    }
+}
+
+// The same append for the list a workgroup is left with when it has run out of tiles (the common case: ~1000 hits,
+// all 256 workgroups at once).  One device-scope atomic per hit made that moment ~0.12 ms of every launch, whatever
+// the row count (profiles/r1/v5_hit_flush_ablation.txt); here the entries are first counted per query in LDS and every
+// query reserves its whole range with ONE atomic.  cnt256 is a scratch of 256 words (the thresholds, dead by now).
+#ifndef CODD_BALLOT_HITS
+#define CODD_BALLOT_HITS 0   // 1: the epilogue reserves LDS hit slots per accumulator block (ballots) instead of per register; measured 2 % slower
+#endif
+#ifndef CODD_BINNED_FLUSH
+#define CODD_BINNED_FLUSH 1
+#endif
+__device__ __forceinline__ void flush_hits_binned(const unsigned* lds_hits, unsigned m, int tid, unsigned* cnt256,
+                                                  u64* __restrict__ hits, unsigned* __restrict__ hit_cnt, int cap_q) {
+    constexpr int kPer = kHitCap / kFilterThreads;
+    static_assert(kHitCap % kFilterThreads == 0, "hit list is a whole number of entries per thread");
+    if (tid < 256) cnt256[tid] = 0u;
+    __syncthreads();
+    unsigned rank[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+        const unsigned e = (unsigned)tid + (unsigned)i * kFilterThreads;
+        rank[i] = e < m ? atomicAdd(&cnt256[lds_hits[e * 3 + 2]], 1u) : 0u;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        const unsigned c = cnt256[tid];
+        cnt256[tid] = c ? atomicAdd(&hit_cnt[tid * kHitCntStride], c) : 0u;  // a poisoned counter stays poisoned
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+        const unsigned e = (unsigned)tid + (unsigned)i * kFilterThreads;
+        if (e < m) {
+            const unsigned q = lds_hits[e * 3 + 2];
+            const unsigned slot = cnt256[q] + rank[i];
+            if (slot < (unsigned)cap_q) hits[(int64_t)q * cap_q + slot] = make_key(__uint_as_float(lds_hits[e * 3 + 0]), lds_hits[e * 3 + 1]);
+        }
     }
 }
 
@@ -411,6 +460,33 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
 #pragma unroll
                             for (int r = 1; r < kAccRegs; ++r) m = fmaxf(m, acc[rs][qb][r]);
                             if (__any(m >= th)) {
+#if CODD_BALLOT_HITS
+                                // one LDS atomic per block that has hits (lane 0 reserves the block's slots, every
+                                // hit lane finds its own from the ballots) instead of one contended atomic per register
+                                unsigned tot = 0;
+#pragma unroll
+                                for (int r = 0; r < kAccRegs; ++r)
+                                    tot += (unsigned)__popcll(__ballot(acc[rs][qb][r] >= th && row0 + acc_row(r, lane) < n));
+                                unsigned base = 0;
+                                if (lane == 0) base = atomicAdd(&lds_w[256], tot);
+                                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+                                for (int r = 0; r < kAccRegs; ++r) {
+                                    const bool hit = acc[rs][qb][r] >= th && row0 + acc_row(r, lane) < n;
+                                    const unsigned long long mk = __ballot(hit);
+                                    if (hit) {
+                                        const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                                        if (slot < (unsigned)kHitCap) {
+                                            lds_hits[slot * 3 + 0] = __float_as_uint(acc[rs][qb][r]);
+                                            lds_hits[slot * 3 + 1] = (unsigned)(row0 + acc_row(r, lane));
+                                            lds_hits[slot * 3 + 2] = (unsigned)(qbase + qb * kMB);
+                                        } else {
+                                            atomicOr(&hit_cnt[(qbase + qb * kMB) * kHitCntStride], 0x80000000u);  // see below
+                                        }
+                                    }
+                                    base += (unsigned)__popcll(mk);
+                                }
+#else
 #pragma unroll
                                 for (int r = 0; r < kAccRegs; ++r) {
                                     const float v = acc[rs][qb][r];
@@ -429,10 +505,11 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                                             // global list from here instead was measured 5 % slower on the whole kernel:
                                             // the extra address arithmetic / call in the epilogue hurts the MFMA loop's
                                             // register allocation.)
-                                            atomicOr(&hit_cnt[qbase + qb * kMB], 0x80000000u);
+                                            atomicOr(&hit_cnt[(qbase + qb * kMB) * kHitCntStride], 0x80000000u);
                                         }
                                     }
                                 }
+#endif
                             }
                         }
                     } else if (MODE == MODE_SAMPLE) {
@@ -473,7 +550,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                 // empty the workgroup's hit list once it is half full
                 const unsigned cnt = lds_w[256];
                 __syncthreads();  // everyone has read cnt before the next epilogue can move it
-                if (cnt > (unsigned)(kHitCap / 2)) {
+                if (cnt > (unsigned)(CODD_FLUSH_AT)) {
                     flush_hits(lds_hits, cnt < (unsigned)kHitCap ? cnt : (unsigned)kHitCap, tid, hits, hit_cnt, cap_q);
                     __syncthreads();
                     if (tid == 0) lds_w[256] = 0u;
@@ -497,7 +574,10 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
         __syncthreads();
         const unsigned cnt = lds_w[256];
         if (cnt > (unsigned)kHitCap && tid == 0) atomicOr(&flags[FLAG_WG_OVERFLOW], 1u);  // statistics only
-        flush_hits(lds_hits, cnt < (unsigned)kHitCap ? cnt : (unsigned)kHitCap, tid, hits, hit_cnt, cap_q);
+        __syncthreads();  // everyone has read cnt (lds_w is about to be reused)
+        if (CODD_EXP_NO_FLUSH) return;
+        if (CODD_BINNED_FLUSH) flush_hits_binned(lds_hits, cnt < (unsigned)kHitCap ? cnt : (unsigned)kHitCap, tid, lds_w, hits, hit_cnt, cap_q);
+        else flush_hits(lds_hits, cnt < (unsigned)kHitCap ? cnt : (unsigned)kHitCap, tid, hits, hit_cnt, cap_q);
     }
 }
 
@@ -550,7 +630,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
     __shared__ float lds_lo;
 
     const int q = blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned total = hit_cnt[q];
+    const unsigned total = hit_cnt[q * kHitCntStride];
     if (total > (unsigned)cap_q) {  // the candidate list was truncated: only the exact scan can answer this query
         if (tid == 0) {
             fb_list[atomicAdd(fb_count, 1u)] = (unsigned)q;

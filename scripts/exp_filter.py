@@ -18,7 +18,8 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "base": {},
-    "blocked": {"CODD_BLOCKED_TILES": 1},
+    "nohits": {"CODD_EXP_NO_HITS": 1},
+    "noballot": {"CODD_BALLOT_HITS": 0},
 }
 
 
