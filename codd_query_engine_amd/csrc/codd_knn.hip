@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <atomic>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -431,7 +432,34 @@ struct FilterCtl {
     unsigned fb_list[kTileQ];  // ... and which ones
 };
 
-struct codd_knn_index {
+// Search workspace.  An index keeps up to kMaxWork of them, one per HIP stream that searches it, so that searches
+// issued on different streams (the next batch while this batch's small kernels and its collective are still in
+// flight) never share scratch memory.  The index inherits one set of these fields: WorkScope loads the calling
+// stream's set into them for the duration of one call and stores it back.
+struct WorkBufs {
+    // (grown on demand, never inside a captured region after warm-up)
+    float* qn = nullptr;       int64_t qn_cap = 0;        // [B][dpad] normalised queries
+    u64* partial = nullptr;    int64_t partial_cap = 0;   // [B][blocks][k]
+    u64* keys_tmp = nullptr;   int64_t keys_tmp_cap = 0;  // [B][k]
+    uint4* qfrag = nullptr;    int64_t qfrag_cap = 0;     // pieces
+    float* thr = nullptr;                                  // [256]
+    float* bucket_max = nullptr; int64_t bucket_cap = 0;   // [sample tiles][256]
+    u64* hits = nullptr;       int64_t hits_cap = 0;      // [256][hit_cap_q]
+    FilterCtl* ctl = nullptr;                              // device
+    u64* fb_partial = nullptr; int64_t fb_partial_cap = 0; // [256][blocks][k] partials of the fallback scan
+    u64* probe_keys = nullptr; int64_t probe_cap = 0;      // IVF: [B][nprobe] coarse keys
+    u64* ivf_partial = nullptr; int64_t ivf_partial_cap = 0;
+};
+constexpr int kMaxWork = 4;
+struct WorkSlot {
+    WorkBufs bufs;
+    hipStream_t stream = nullptr;
+    hipEvent_t handover = nullptr;  // recorded on the old stream when the slot changes hands
+    bool used = false;
+    uint64_t tick = 0;              // last use (LRU)
+};
+
+struct codd_knn_index : WorkBufs {
     int device = 0;
     int dim = 0;
     int dpad = 0;
@@ -455,16 +483,6 @@ struct codd_knn_index {
     int sample_div = 40;      // sample about 1/40 of the tiles (2.5 % extra GEMM work), see sample_tile_count()
     int hit_cap_q = 32768;  // candidates kept per query before it falls back to the exact scan (64 MiB at 256 queries)
 
-    // workspaces (grown on demand, never inside a captured region after warm-up)
-    float* qn = nullptr;       int64_t qn_cap = 0;        // [B][dpad] normalised queries
-    u64* partial = nullptr;    int64_t partial_cap = 0;   // [B][blocks][k]
-    u64* keys_tmp = nullptr;   int64_t keys_tmp_cap = 0;  // [B][k]
-    uint4* qfrag = nullptr;    int64_t qfrag_cap = 0;     // pieces
-    float* thr = nullptr;                                  // [256]
-    float* bucket_max = nullptr; int64_t bucket_cap = 0;   // [sample tiles][256]
-    u64* hits = nullptr;       int64_t hits_cap = 0;      // [256][hit_cap_q]
-    FilterCtl* ctl = nullptr;                              // device
-    u64* fb_partial = nullptr; int64_t fb_partial_cap = 0; // [256][blocks][k] partials of the fallback scan
     unsigned long long* dstats = nullptr;                  // device counters: hits, survivors, fallback queries
 
     // IVF (optional): rows regrouped by coarse list, original slots, list offsets, the coarse index
@@ -475,8 +493,6 @@ struct codd_knn_index {
     int64_t ivf_count = 0;             // rows covered by the IVF layout (must equal count to be fresh)
     int ivf_nlist = 0;
     int64_t ivf_epoch = -1, epoch = 0;  // epoch bumps on every row write; search requires ivf_epoch == epoch
-    u64* probe_keys = nullptr; int64_t probe_cap = 0;
-    u64* ivf_partial = nullptr; int64_t ivf_partial_cap = 0;
 
     int64_t stat_searches = 0, stat_scan_launches = 0, stat_last_scan_blocks = 0;
     int64_t stat_filter_passes = 0;
@@ -487,6 +503,10 @@ struct codd_knn_index {
     std::vector<hipEvent_t> ev;  // 2 * pairs
     std::vector<int> ev_kind;
     int ev_used = 0;
+
+    WorkSlot slots[kMaxWork];
+    uint64_t tick = 0;
+    std::mutex mu;  // one host thread at a time enqueues a search (the launches themselves are asynchronous)
 };
 
 namespace {
@@ -532,6 +552,49 @@ struct EvScope {  // records a (start, stop) pair around one launch when profili
     ~EvScope() {
         if (slot >= 0) (void)hipEventRecord(ix->ev[2 * slot + 1], st);
     }
+};
+
+// Loads the calling stream's workspace into the index for one call (see WorkBufs).  A stream keeps its slot; a new
+// stream takes a free slot, or the least recently used one after making itself wait for everything the previous
+// owner has enqueued so far (no host synchronisation; if that stream no longer exists the device is drained instead).
+struct WorkScope {
+    codd_knn_index* ix;
+    int slot = 0;
+    WorkScope(codd_knn_index* ix_, hipStream_t st) : ix(ix_) {
+        ix->mu.lock();
+        int free_slot = -1, lru = 0;
+        slot = -1;
+        for (int i = 0; i < kMaxWork; ++i) {
+            WorkSlot& w = ix->slots[i];
+            if (w.used && w.stream == st) { slot = i; break; }
+            if (!w.used && free_slot < 0) free_slot = i;
+            if (w.used && ix->slots[lru].used && w.tick < ix->slots[lru].tick) lru = i;
+        }
+        if (slot < 0 && free_slot >= 0) slot = free_slot;
+        if (slot < 0) {
+            slot = lru;
+            WorkSlot& w = ix->slots[slot];
+            bool ordered = false;
+            if (!w.handover) (void)hipEventCreateWithFlags(&w.handover, hipEventDisableTiming);
+            if (w.handover && hipEventRecord(w.handover, w.stream) == hipSuccess) ordered = hipStreamWaitEvent(st, w.handover, 0) == hipSuccess;
+            if (!ordered) {
+                (void)hipGetLastError();
+                (void)hipDeviceSynchronize();
+            }
+        }
+        WorkSlot& w = ix->slots[slot];
+        w.used = true;
+        w.stream = st;
+        w.tick = ++ix->tick;
+        static_cast<WorkBufs&>(*ix) = w.bufs;
+    }
+    ~WorkScope() {
+        ix->slots[slot].bufs = static_cast<WorkBufs&>(*ix);
+        static_cast<WorkBufs&>(*ix) = WorkBufs();
+        ix->mu.unlock();
+    }
+    WorkScope(const WorkScope&) = delete;
+    WorkScope& operator=(const WorkScope&) = delete;
 };
 
 size_t elem_size(int dtype) { return dtype == DT_F32 ? 4 : 2; }
@@ -1004,13 +1067,16 @@ int codd_knn_destroy(codd_knn_index* ix) {
     if (!ix) return CODD_KNN_OK;
     DeviceGuard guard(ix->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = {ix->rows, ix->shadow, ix->qn, ix->partial, ix->keys_tmp, ix->qfrag, ix->thr, ix->bucket_max,
-                    ix->hits, ix->ctl, ix->fb_partial, ix->dstats};
+    void* bufs[] = {ix->rows, ix->shadow, ix->dstats, ix->rows_ivf, ix->ivf_ids, ix->ivf_offsets};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
-    void* ivf_bufs[] = {ix->rows_ivf, ix->ivf_ids, ix->ivf_offsets, ix->probe_keys, ix->ivf_partial};
-    for (void* b : ivf_bufs)
-        if (b) (void)hipFree(b);
+    for (WorkSlot& w : ix->slots) {
+        void* wb[] = {w.bufs.qn, w.bufs.partial, w.bufs.keys_tmp, w.bufs.qfrag, w.bufs.thr, w.bufs.bucket_max, w.bufs.hits, w.bufs.ctl,
+                      w.bufs.fb_partial, w.bufs.probe_keys, w.bufs.ivf_partial};
+        for (void* b : wb)
+            if (b) (void)hipFree(b);
+        if (w.handover) (void)hipEventDestroy(w.handover);
+    }
     if (ix->coarse) (void)codd_knn_destroy(ix->coarse);
     for (hipEvent_t e : ix->ev) (void)hipEventDestroy(e);
     delete ix;
@@ -1139,12 +1205,16 @@ int codd_knn_read_rows(const codd_knn_index* ix, int64_t first, int64_t n, void*
 
 int codd_knn_search(codd_knn_index* ix, const float* dev_queries, int B, int k, float* dev_dist, int64_t* dev_rows, void* stream) {
     if (!dev_dist || !dev_rows) return fail(CODD_KNN_EINVAL, "null output%s");
+    if (!ix) return fail(CODD_KNN_EINVAL, "null index%s");
+    WorkScope work(ix, (hipStream_t)stream);
     return search_impl(ix, dev_queries, B, k, 0u, nullptr, dev_dist, dev_rows, (hipStream_t)stream);
 }
 
 int codd_knn_search_keys(codd_knn_index* ix, const float* dev_queries, int B, int k, uint32_t row_base, uint64_t* dev_keys, void* stream) {
     if (!dev_keys) return fail(CODD_KNN_EINVAL, "null output%s");
-    if (ix && (int64_t)row_base + ix->count >= 0xffffffffll) return fail(CODD_KNN_EINVAL, "global row ids must fit 32 bits%s");
+    if (!ix) return fail(CODD_KNN_EINVAL, "null index%s");
+    if ((int64_t)row_base + ix->count >= 0xffffffffll) return fail(CODD_KNN_EINVAL, "global row ids must fit 32 bits%s");
+    WorkScope work(ix, (hipStream_t)stream);
     return search_impl(ix, dev_queries, B, k, row_base, (u64*)dev_keys, nullptr, nullptr, (hipStream_t)stream);
 }
 
@@ -1160,6 +1230,7 @@ int codd_knn_approx_scores(codd_knn_index* ix, const float* dev_queries, int B, 
     if (ix->count < 1 || !ix->shadow) return fail(CODD_KNN_EINVAL, "empty index%s");
     DeviceGuard guard(ix->device);
     hipStream_t st = (hipStream_t)stream;
+    WorkScope work(ix, st);
     int rc;
     if ((rc = ensure_buf(&ix->qn, &ix->qn_cap, (int64_t)B * ix->dpad)) != 0) return rc;
     if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
@@ -1234,6 +1305,7 @@ int codd_knn_ivf_search(codd_knn_index* ix, const float* dev_queries, int B, int
     if (nprobe > CODD_KNN_MAX_K) return fail(CODD_KNN_ENOTSUP, "nprobe above 128 is not supported (probe the whole index with codd_knn_search)%s");
     DeviceGuard guard(ix->device);
     hipStream_t st = (hipStream_t)stream;
+    WorkScope work(ix, st), work_coarse(ix->coarse, st);
     int rc;
     if ((rc = ensure_buf(&ix->qn, &ix->qn_cap, (int64_t)B * ix->dpad)) != 0) return rc;
     if ((rc = ensure_buf(&ix->probe_keys, &ix->probe_cap, (int64_t)B * nprobe)) != 0) return rc;
@@ -1357,9 +1429,17 @@ int codd_knn_get_stat(const codd_knn_index* ix, const char* key, int64_t* out) {
     }
     else if (strcmp(key, "capacity_rows") == 0) *out = ix->capacity;
     else if (strcmp(key, "num_cus") == 0) *out = ix->num_cus;
-    else if (strcmp(key, "device_bytes") == 0)
-        *out = ix->capacity * (int64_t)ix->dpad * (int64_t)elem_size(ix->dtype) + ix->shadow_rows * (int64_t)ix->dpad * 2 +
-               ix->qn_cap * 4 + ix->partial_cap * 8 + ix->keys_tmp_cap * 8 + ix->hits_cap * 8 + ix->bucket_cap * 4 + ix->qfrag_cap * 16;
+    else if (strcmp(key, "device_bytes") == 0) {
+        int64_t b = ix->capacity * (int64_t)ix->dpad * (int64_t)elem_size(ix->dtype) + ix->shadow_rows * (int64_t)ix->dpad * 2;
+        for (const WorkSlot& w : ix->slots)
+            b += w.bufs.qn_cap * 4 + w.bufs.partial_cap * 8 + w.bufs.keys_tmp_cap * 8 + w.bufs.hits_cap * 8 + w.bufs.bucket_cap * 4 +
+                 w.bufs.qfrag_cap * 16 + w.bufs.fb_partial_cap * 8 + w.bufs.probe_cap * 8 + w.bufs.ivf_partial_cap * 8;
+        *out = b;
+    } else if (strcmp(key, "workspaces") == 0) {
+        int64_t c = 0;
+        for (const WorkSlot& w : ix->slots) c += w.used ? 1 : 0;
+        *out = c;
+    }
     else return fail(CODD_KNN_EINVAL, "unknown stat: %s", key);
     return CODD_KNN_OK;
 }

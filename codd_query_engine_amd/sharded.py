@@ -30,6 +30,24 @@ def shard_bounds(n_total: int, world_size: int, rank: int) -> tuple[int, int]:
     return begin, min(n_total, begin + per)
 
 
+class PendingSearch:
+    """Handle of ShardedSearcher.search_async: the results live on a side stream until `.result()`."""
+
+    def __init__(self, stream: Any, out: tuple):
+        self._stream, self._out = stream, out
+
+    def result(self) -> tuple:
+        if self._stream is not None:
+            import torch
+
+            cur = torch.cuda.current_stream(self._out[0].device)
+            cur.wait_stream(self._stream)
+            for t in self._out:
+                t.record_stream(cur)
+            self._stream = None
+        return self._out
+
+
 class ShardedSearcher:
     """Glue between a shard-local engine and the process group.
 
@@ -54,9 +72,34 @@ class ShardedSearcher:
 
             merge = hip_merge
         self._merge = merge
+        self._streams: list = []
+        self._turn = 0
 
     def search_keys_local(self, queries, k: int):
         return self.engine.search_keys(queries, k, self.row_base)
+
+    def search_async(self, queries, k: int, depth: int = 2) -> "PendingSearch":
+        """Issue one batch on a side stream and return at once; `.result()` makes the caller's stream wait for it.
+
+        Consecutive batches go to `depth` alternating HIP streams, so the small kernels, the all_gather and the merge
+        of batch i overlap the filter kernel of batch i+1 (the engine keeps one workspace per stream).  Every rank must
+        issue its batches in the same order, as with `search`.  With a host engine (gloo tests) it runs synchronously.
+        """
+        import torch
+
+        dev = getattr(queries, "device", None)
+        if not (isinstance(queries, torch.Tensor) and dev is not None and dev.type == "cuda"):
+            return PendingSearch(None, self.search(queries, k))
+        if len(self._streams) != depth:
+            self._streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+            self._turn = 0
+        side = self._streams[self._turn]
+        self._turn = (self._turn + 1) % depth
+        side.wait_stream(torch.cuda.current_stream(dev))  # the queries are ready
+        with torch.cuda.stream(side):
+            out = self.search(queries, k)
+        queries.record_stream(side)
+        return PendingSearch(side, out)
 
     def search(self, queries, k: int):
         """(dist [B,k], global rows [B,k]) — identical on every rank."""

@@ -19,8 +19,13 @@
  *     the index owns its row storage and its workspaces.
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls
  *     are asynchronous with respect to the host unless stated otherwise.
- *   - thread-safety: searches on distinct streams may run concurrently only on
- *     distinct indexes (an index owns one workspace); upsert/reserve are exclusive.
+ *   - thread-safety: the search entry points (codd_knn_search, _search_keys,
+ *     _ivf_search, _approx_scores) may be called from several host threads and on
+ *     several streams of one index: the index keeps one workspace per stream (up to
+ *     4; a fifth stream takes over the least recently used one, ordered behind its
+ *     previous owner on the device) and serialises only the enqueueing.  Searches on
+ *     different streams then overlap on the GPU.  upsert/reserve/load/ivf_install
+ *     are exclusive: no other call on the index may be in flight.
  *   - rows are stored L2-normalised, zero padded to a multiple of 64 elements.
  *     score = <q/|q|, c/|c|> evaluated in fp32 in the canonical order of
  *     DESIGN.md §3; distance = 1 - score (fp32); ties -> lower row.
@@ -163,7 +168,7 @@ int codd_knn_ivf_search(codd_knn_index* index, const float* dev_queries, int B, 
  *            recorded on the launch stream (0 = off; resets the log)
  *   stats  : "searches", "scan_launches", "last_scan_blocks", "filter_passes",
  *            "fallback_queries", "filter_hits", "filter_survivors", "capacity_rows",
- *            "device_bytes", "num_cus", and per kernel K in {scan, filter, sample, finalize}:
+ *            "device_bytes", "num_cus", "workspaces" (stream workspaces in use), and per kernel K in {scan, filter, sample, finalize}:
  *            "events:K", "time_ns:K" (sum of the recorded launches; syncs on the last event)
  */
 int codd_knn_set_option(codd_knn_index* index, const char* key, int64_t value);

@@ -22,6 +22,13 @@ def Index():
     return DeviceKnnIndex
 
 
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+
+    return torch
+
+
 def build(Index, raw, dtype="f32", force_filter=True):
     ix = Index(raw.shape[1], dtype=dtype)
     ix.upsert(np.arange(raw.shape[0], dtype=np.int64), raw)
@@ -298,4 +305,49 @@ def test_unnormalised_rows_disable_the_filter(Index):
     ix.upsert(np.arange(40_000, dtype=np.int64), raw, normalize=False)  # caller's own scaling: no unit-norm bound
     ix.search(rng.standard_normal((32, 128)).astype(np.float32), 5)
     assert ix.stat("filter_passes") == 0
+    ix.close()
+
+
+def test_searches_on_several_streams_use_their_own_workspaces(Index, torch):
+    """The next batch may be issued on another stream while the previous one is still in flight (bench.py's sharded
+    loop does): every stream gets its own workspace, a fifth stream takes over the least recently used one."""
+    rng = np.random.default_rng(77)
+    raw = rng.standard_normal((60_000, 256)).astype(np.float32)
+    ix = Index(256)
+    ix.upsert(np.arange(raw.shape[0], dtype=np.int64), raw)
+    qs = [torch.from_numpy(rng.standard_normal((b, 256)).astype(np.float32)).cuda() for b in (256, 40, 1, 130, 256, 9)]
+    ref = [ix.search_tensors(q, 10) for q in qs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(6)]
+    cur = torch.cuda.current_stream()
+    outs = []
+    for rep in range(5):
+        for i, q in enumerate(qs):
+            s = streams[(i + rep) % len(streams)]
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                outs.append((i, ix.search_tensors(q, 10)))
+    for s in streams:
+        cur.wait_stream(s)
+    torch.cuda.synchronize()
+    assert ix.stat("workspaces") == 4
+    for i, (d, r) in outs:
+        assert torch.equal(r, ref[i][1]) and torch.equal(d, ref[i][0])
+    ix.close()
+
+
+def test_search_async_pipelines_batches(Index, torch):
+    from codd_query_engine_amd.sharded import ShardedSearcher
+
+    rng = np.random.default_rng(78)
+    raw = rng.standard_normal((30_000, 128)).astype(np.float32)
+    ix = Index(128)
+    ix.upsert(np.arange(raw.shape[0], dtype=np.int64), raw)
+    searcher = ShardedSearcher(ix, row_base=0)
+    qs = [torch.from_numpy(rng.standard_normal((64, 128)).astype(np.float32)).cuda() for _ in range(7)]
+    ref = [searcher.search(q, 10) for q in qs]
+    pending = [searcher.search_async(q, 10, depth=2) for q in qs]
+    for h, (d_ref, r_ref) in zip(pending, ref):
+        d, r = h.result()
+        assert torch.equal(r, r_ref) and torch.equal(d, d_ref)
     ix.close()

@@ -60,6 +60,8 @@ def worker(rank, world, port, n, d, B, k, out_dir):
             eng.upsert(np.arange(hi - lo, dtype=np.int64), raw[lo:hi])
         searcher = ShardedSearcher(TensorOracleEngine(eng), row_base=lo, merge=oracle_merge)
         dd, rr = searcher.search(q, k)
+        dd2, rr2 = searcher.search_async(q, k).result()  # host engine: runs synchronously, same collective order on all ranks
+        assert torch.equal(dd, dd2) and torch.equal(rr, rr2)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), dist=dd.numpy(), rows=rr.numpy())
     finally:
         dist.destroy_process_group()
