@@ -43,6 +43,49 @@ namespace {
 // IEEE division per element; a zero / non-finite norm stores an all-zero row.
 // shadow (optional): the bf16 rounding of the STORED value, in fragment order (filter_gemm.h).
 // ---------------------------------------------------------------------------------------------
+// |x| of one vector by the canonical sum of squares: chunk j of 4 elements belongs to lane j % 64
+__device__ __forceinline__ float canonical_norm(const float* __restrict__ x, int d, int nch, int lane) {
+    float acc = 0.0f;
+    for (int j = lane; j < nch; j += kWave) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = j * 4 + e;
+            const float v = i < d ? x[i] : 0.0f;
+            acc = __builtin_fmaf(v, v, acc);
+        }
+    }
+    return __builtin_sqrtf(butterfly_sum(acc));
+}
+
+// Query preparation of one filter pass in ONE launch (B <= 256): q <- q/|q| exactly as normalize_rows_kernel<f32> does
+// (qn, for finalize's exact re-scoring), the same values rounded into the MFMA fragment order (qfrag; queries >= B
+// are zero), and the pass's control block cleared.  One wave per query slot, 64 blocks.
+__global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ in, int B, int d, int dpad, float* __restrict__ qn,
+                                                           uint2* __restrict__ qfrag, unsigned* __restrict__ ctl, int ctl_words) {
+    const int lane = lane_id();
+    const int q = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    for (int i = (int)blockIdx.x * 256 + (int)threadIdx.x; i < ctl_words; i += (int)gridDim.x * 256) ctl[i] = 0u;
+    const int nch = dpad >> 2;
+    if (q >= B) {
+        for (int j = lane; j < nch; j += kWave) qfrag[codd::qfrag_piece_index(q, j >> 1) * 2 + (j & 1)] = make_uint2(0u, 0u);
+        return;
+    }
+    const float* x = in + (int64_t)q * d;
+    const float nrm = canonical_norm(x, d, nch, lane);
+    const bool zero_row = !(nrm > 0.0f) || !(nrm < INFINITY);
+    for (int j = lane; j < nch; j += kWave) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = j * 4 + e;
+            const float t = i < d ? x[i] : 0.0f;
+            v[e] = zero_row ? 0.0f : t / nrm;
+        }
+        reinterpret_cast<float4*>(qn)[(int64_t)q * nch + j] = make_float4(v[0], v[1], v[2], v[3]);
+        qfrag[codd::qfrag_piece_index(q, j >> 1) * 2 + (j & 1)] = make_uint2(codd::pack_bf16x2(v[0], v[1]), codd::pack_bf16x2(v[2], v[3]));
+    }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ in, int64_t n, int d, int dpad,
                                                              int normalize, const int64_t* __restrict__ slots,
@@ -57,17 +100,7 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
     float scale_div = 1.0f;
     bool zero_row = false;
     if (normalize) {
-        float acc = 0.0f;
-        for (int j = lane; j < nch; j += kWave) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = j * 4 + e;
-                const float v = i < d ? x[i] : 0.0f;
-                acc = __builtin_fmaf(v, v, acc);
-            }
-        }
-        const float n2 = butterfly_sum(acc);
-        const float nrm = __builtin_sqrtf(n2);
+        const float nrm = canonical_norm(x, d, nch, lane);
         zero_row = !(nrm > 0.0f) || !(nrm < INFINITY);
         scale_div = nrm;
     }
@@ -877,7 +910,8 @@ int64_t sample_tile_count(const codd_knn_index* ix, int64_t ntiles, int k) {
 }
 
 // one pass of <= 256 queries through sample -> threshold -> filter -> finalize (+ exact fallback)
-int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row_base, u64* keys_out, hipStream_t st) {
+int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row_base, u64* keys_out, hipStream_t st,
+                bool prepared = false) {
     const int64_t n = ix->count;
     const int nsteps = ix->dpad / 64;
     const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
@@ -886,9 +920,11 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     int rc;
     ix->stat_filter_passes++;
 
-    hipLaunchKernelGGL(qfrag_kernel, dim3((kTileQ * (ix->dpad / 8) + 255) / 256), dim3(256), 0, st, qn, nq, ix->dpad, ix->qfrag,
-                       reinterpret_cast<unsigned*>(ix->ctl), (int)(sizeof(FilterCtl) / 4));
-    HIP_TRY(hipGetLastError());
+    if (!prepared) {  // (a batch of <= 256 queries arrives with its fragments and a cleared control block: prep_queries_kernel)
+        hipLaunchKernelGGL(qfrag_kernel, dim3((kTileQ * (ix->dpad / 8) + 255) / 256), dim3(256), 0, st, qn, nq, ix->dpad, ix->qfrag,
+                           reinterpret_cast<unsigned*>(ix->ctl), (int)(sizeof(FilterCtl) / 4));
+        HIP_TRY(hipGetLastError());
+    }
 
     // sample: every `stride`-th tile
     const int64_t ts = sample_tile_count(ix, ntiles, k);
@@ -995,7 +1031,16 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
     int rc;
     if ((rc = ensure_buf(&ix->qn, &ix->qn_cap, (int64_t)B * ix->dpad)) != 0) return rc;
     if ((rc = ensure_buf(&ix->keys_tmp, &ix->keys_tmp_cap, (int64_t)B * k)) != 0) return rc;
-    if ((rc = launch_normalize(DT_F32, dev_queries, B, ix->dim, ix->dpad, 1, nullptr, 0, ix->qn, nullptr, st)) != 0) return rc;
+    const bool use_filter = n > 0 && filter_applies(ix, B, k);
+    const bool fused_prep = use_filter && B <= kTileQ;
+    if (fused_prep) {
+        if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
+        hipLaunchKernelGGL(prep_queries_kernel, dim3(kTileQ / 4), dim3(256), 0, st, dev_queries, B, ix->dim, ix->dpad, ix->qn,
+                           reinterpret_cast<uint2*>(ix->qfrag), reinterpret_cast<unsigned*>(ix->ctl), (int)(sizeof(FilterCtl) / 4));
+        HIP_TRY(hipGetLastError());
+    } else if ((rc = launch_normalize(DT_F32, dev_queries, B, ix->dim, ix->dpad, 1, nullptr, 0, ix->qn, nullptr, st)) != 0) {
+        return rc;
+    }
 
     // the filter passes write keys; when the caller wants only keys (the shard-local half of a sharded
     // search) they go straight into its buffer and the unpack launch below is skipped
@@ -1004,11 +1049,12 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
     if (n == 0) {
         // nothing stored: all-empty result (chromadb returns {"ids": [[]], ...})
         HIP_TRY(hipMemsetAsync(keys_dst, 0, (size_t)B * k * sizeof(u64), st));
-    } else if (filter_applies(ix, B, k)) {
+    } else if (use_filter) {
         if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
         for (int q0 = 0; q0 < B; q0 += kTileQ) {
             const int nq = B - q0 < kTileQ ? B - q0 : kTileQ;
-            if ((rc = filter_pass(ix, ix->qn + (int64_t)q0 * ix->dpad, nq, k, row_base, keys_dst + (int64_t)q0 * k, st)) != 0) return rc;
+            if ((rc = filter_pass(ix, ix->qn + (int64_t)q0 * ix->dpad, nq, k, row_base, keys_dst + (int64_t)q0 * k, st, fused_prep)) != 0)
+                return rc;
         }
     } else {
         // small batches: the per-block partials merge straight into the caller's buffers
