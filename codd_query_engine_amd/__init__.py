@@ -8,7 +8,7 @@ hand-written HIP (csrc/) behind the C ABI of include/codd_knn.h.
 
 from .errors import ValidationError
 from .models import MetricMetadata, SearchResult, SemanticStoreConfig
-from .embedding import HashingEmbeddingFunction
+from .embedding import HashingEmbeddingFunction, LocalTransformerEmbeddingFunction
 from .knn_client import Collection, KnnClient
 from .semantic_store import MetricsSemanticMetadataStore
 from .metrics_search import MetricsSearchClient, get_semantic_store, project_search_results
@@ -19,6 +19,7 @@ __all__ = [
     "SearchResult",
     "SemanticStoreConfig",
     "HashingEmbeddingFunction",
+    "LocalTransformerEmbeddingFunction",
     "Collection",
     "KnnClient",
     "MetricsSemanticMetadataStore",

@@ -51,3 +51,52 @@ class HashingEmbeddingFunction:
         if len(texts) == 0:
             return np.zeros((0, self.dim), dtype=np.float32)
         return np.stack([self.embed_one(t) for t in texts]).astype(np.float32)
+
+
+class LocalTransformerEmbeddingFunction:
+    """Sentence embeddings from a transformer encoder stored in a LOCAL directory (nothing is downloaded).
+
+    The counterpart of chromadb's default embedder for installations that have the all-MiniLM-L6-v2 files (or any
+    BERT-style encoder in Hugging Face layout: config.json, tokenizer files, weights) on disk: tokenise, run the
+    encoder with torch (on the GPU when `device` is a cuda device, so text -> vector -> top-k stays on one device),
+    mean-pool the last hidden states over the attention mask and L2-normalise — the pooling the sentence-transformers
+    MiniLM family is trained with.  Returns float32 [n, hidden_size].
+
+    Loading uses `local_files_only=True` and safetensors / `weights_only` checkpoints only; a missing directory is an
+    error, never a fetch.
+    """
+
+    def __init__(self, model_dir: str, device: str = "cpu", max_length: int = 256, batch_size: int = 64):
+        import os
+
+        if not os.path.isdir(model_dir):
+            raise FileNotFoundError(f"no model directory at {model_dir!r} (this embedder never downloads)")
+        import torch
+        from transformers import AutoModel, AutoTokenizer
+
+        self._torch = torch
+        self.device = torch.device(device)
+        self.max_length = int(max_length)
+        self.batch_size = int(batch_size)
+        self.tokenizer = AutoTokenizer.from_pretrained(model_dir, local_files_only=True)
+        self.model = AutoModel.from_pretrained(model_dir, local_files_only=True).to(self.device).eval()
+        self.dim = int(self.model.config.hidden_size)
+
+    def embed_tensor(self, texts: Sequence[str]):
+        """[n, dim] float32 tensor on `self.device` (what a device-resident pipeline feeds to search_tensors)."""
+        torch = self._torch
+        out = []
+        with torch.inference_mode():
+            for i in range(0, len(texts), self.batch_size):
+                enc = self.tokenizer(list(texts[i : i + self.batch_size]), padding=True, truncation=True, max_length=self.max_length,
+                                     return_tensors="pt").to(self.device)
+                hidden = self.model(**enc).last_hidden_state.float()
+                mask = enc["attention_mask"].unsqueeze(-1).float()
+                pooled = (hidden * mask).sum(1) / mask.sum(1).clamp(min=1e-9)
+                out.append(torch.nn.functional.normalize(pooled, p=2, dim=1))
+        if not out:
+            return torch.zeros((0, self.dim), dtype=torch.float32, device=self.device)
+        return torch.cat(out, 0)
+
+    def __call__(self, texts: Sequence[str]) -> np.ndarray:
+        return self.embed_tensor(texts).cpu().numpy().astype(np.float32)
