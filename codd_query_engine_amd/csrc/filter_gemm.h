@@ -28,6 +28,8 @@
 //     the kernel is an ordinary counted load and __syncthreads() stays a bare s_barrier;
 //   * one barrier per stage; 64 MFMAs + 32 ds_read_b128 per wave per K-step.
 #pragma once
+#include <type_traits>
+
 #include "row_traits.h"
 #include "wave_topk.h"
 
@@ -139,6 +141,11 @@ constexpr int kHitCntStride = CODD_HITCNT_STRIDE;
 #ifndef CODD_RING
 #define CODD_RING 3
 #endif
+#ifndef CODD_QDEPTH
+#define CODD_QDEPTH 1   // 2: the query slice of step t+3 is requested during step t (one step more for the L2 round trip), 16 more VGPRs
+#endif
+constexpr int kQD = CODD_QDEPTH;
+constexpr int kUnroll = CODD_RING * CODD_QDEPTH;  // steps per unrolled loop body: every register buffer index is static
 constexpr int kRing = CODD_RING;        // corpus-fragment register ring (K-steps)
 constexpr int kPrefetch = CODD_RING - 1;  // K-steps the corpus loads run ahead
 
@@ -201,6 +208,15 @@ __global__ __launch_bounds__(256) void qfrag_kernel(const float* __restrict__ qn
         v = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
     }
     qfrag[qfrag_piece_index(q, c8)] = v;
+}
+
+// f(integral_constant<int, 0>{}) ... f(integral_constant<int, N-1>{}), in order
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
 }
 
 // append a workgroup's LDS hit list (entries: score bits, row, query) to the per-query global lists
@@ -349,15 +365,23 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
     // every thread stages (loads are unconditional, see load_a); when the slice has fewer pieces than
     // threads, two threads copy the same piece to the same place
     const int stid = kSP >= kFilterThreads ? tid : tid % kSP;
+    typedef unsigned q4u __attribute__((ext_vector_type(4)));  // (native vectors: uint4 staging buffers end up as scratch allocas)
 #pragma unroll
     for (int sub = 0; sub < kQS; ++sub) {
         const uint4* src = qfrag + (int64_t)q_s * kStagePieces + stid;
         uint4* dst = ldsQ + sub * kStagePieces + stid;
-        uint4 tmp[kQPn];
+        q4u tmp[kQPn];
 #pragma unroll
-        for (int j = 0; j < kQPn; ++j) tmp[j] = src[j * kFilterThreads];
+        for (int j = 0; j < kQPn; ++j) tmp[j] = reinterpret_cast<const q4u*>(src)[j * kFilterThreads];
 #pragma unroll
-        for (int j = 0; j < kQPn; ++j) dst[j * kFilterThreads] = tmp[j];
+        for (int j = 0; j < kQPn; ++j) reinterpret_cast<q4u*>(dst)[j * kFilterThreads] = tmp[j];
+        q_s = q_s + 1 == nsteps ? 0 : q_s + 1;
+    }
+    q4u qreg0[kQPn], qreg1[kQPn];
+    if (kQD == 2) {  // the slice step 0 will write to LDS is already on its way
+        const uint4* src = qfrag + (int64_t)q_s * kStagePieces + stid;
+#pragma unroll
+        for (int j = 0; j < kQPn; ++j) qreg1[j] = reinterpret_cast<const q4u*>(src)[j * kFilterThreads];
         q_s = q_s + 1 == nsteps ? 0 : q_s + 1;
     }
     __syncthreads();
@@ -373,19 +397,21 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
     // T is walked in whole rings: the (at most kRing-1) padding steps past T recompute the last slice
     // into accumulators nobody reads (`live` gates every side effect), which keeps the loop free of
     // early exits and lets every load stay unconditional
-    for (int t0 = 0; t0 < T; t0 += kRing) {
-#pragma unroll
-        for (int i = 0; i < kRing; ++i) {
-            const int t = t0 + i;
+    for (int t0 = 0; t0 < T; t0 += kUnroll) {
+        // one K-step; IU (position inside the unrolled body) is a compile-time constant, so every register buffer
+        // (corpus ring slot, query staging buffer) is chosen by the front end, not by an optimisation pass
+        auto k_step = [&](auto IU) __attribute__((always_inline)) {
+            constexpr int iu = decltype(IU)::value;
+            constexpr int i = iu % kRing;
+            const int t = t0 + iu;
             const bool live = t < T;
             const int stage = t / kQS, sub = t % kQS;
             // query slice of step t+kQS: issue now, write to LDS after the MFMAs
-            uint4 qreg[kQPn];
             {
                 const uint4* src = qfrag + (int64_t)q_s * kStagePieces + stid;
                 if (!CODD_EXP_NO_QSTAGE) {
 #pragma unroll
-                    for (int j = 0; j < kQPn; ++j) qreg[j] = src[j * kFilterThreads];
+                    for (int j = 0; j < kQPn; ++j) (iu % kQD ? qreg1 : qreg0)[j] = reinterpret_cast<const q4u*>(src)[j * kFilterThreads];
                 }
                 q_s = q_s + 1 == nsteps ? 0 : q_s + 1;
             }
@@ -440,7 +466,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                 uint4* dstq = ldsQ + (((stage + 1) & 1) * kQS + sub) * kStagePieces + stid;
                 if (!CODD_EXP_NO_QSTAGE) {
 #pragma unroll
-                    for (int j = 0; j < kQPn; ++j) dstq[j * kFilterThreads] = qreg[j];
+                    for (int j = 0; j < kQPn; ++j) reinterpret_cast<q4u*>(dstq)[j * kFilterThreads] = ((iu + kQD - 1) % kQD ? qreg1 : qreg0)[j];
                 }
             }
 
@@ -567,7 +593,8 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                 __syncthreads();
             }
             if (++c_s == nsteps) { c_s = 0; c_u += step_u; }
-        }
+        };
+        static_for<kUnroll>(k_step);
     }
 
     if (MODE == MODE_FILTER) {

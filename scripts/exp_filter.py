@@ -18,8 +18,7 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "base": {},
-    "nohits": {"CODD_EXP_NO_HITS": 1},
-    "noballot": {"CODD_BALLOT_HITS": 0},
+    "qd2": {"CODD_QDEPTH": 2},
 }
 
 
