@@ -109,3 +109,29 @@ def search_ivf(index: DeviceKnnIndex, queries, k: int, nprobe: int, row_base: in
         "codd_knn_ivf_search",
     )
     return dist, rows
+
+
+def search_ivf_keys(index: DeviceKnnIndex, queries, k: int, nprobe: int, row_base: int = 0):
+    """Shard-local half of a row-sharded IVF search: [B,k] packed keys carrying GLOBAL rows (as codd_knn_search_keys)."""
+    import torch
+
+    lib = native.load()
+    q = index._queries_tensor(queries)
+    B = q.shape[0]
+    keys = torch.empty((B, k), dtype=torch.int64, device=index.device)
+    native.check(
+        lib.codd_knn_ivf_search(index._h, q.data_ptr(), B, int(k), int(nprobe), int(row_base), keys.data_ptr(), None, None, index._stream()),
+        "codd_knn_ivf_search",
+    )
+    return keys
+
+
+class IvfShardEngine:
+    """What ShardedSearcher needs from an engine, answered by the shard's IVF lists (BASELINE configs[4]: every rank
+    builds an IVF over its own rows; the exchange is the same all_gather of B*k keys as for the flat search)."""
+
+    def __init__(self, index: DeviceKnnIndex, nprobe: int):
+        self.index, self.nprobe = index, int(nprobe)
+
+    def search_keys(self, queries, k: int, row_base: int = 0):
+        return search_ivf_keys(self.index, queries, k, self.nprobe, row_base)

@@ -73,3 +73,35 @@ def test_recall_on_clustered_data_and_staleness(env):
     with pytest.raises(NativeLibraryError):
         ivf.search_ivf(ix, q, k, 8)
     ix.close()
+
+
+def test_two_ivf_shards_merge_to_the_whole_answer(env):
+    """configs[4]'s composition on one GPU: two shards, each with its own IVF, probed exhaustively, keys carrying global
+    rows, merged by codd_knn_merge_keys == the flat search over all rows (the cross-rank gather is covered by the gloo tests)."""
+    torch, Index, ivf = env
+    from codd_query_engine_amd.sharded import ShardedSearcher
+
+    n, d, k, cut = 30_000, 128, 10, 13_000
+    x = clustered(torch, n, d, 64).contiguous()
+    whole = Index(d, "f16")
+    whole.upsert_device(0, x)
+    q = clustered(torch, 17, d, 64, seed=5)
+    d_ref, r_ref = whole.search_tensors(q, k)
+    shards = []
+    for lo, hi in ((0, cut), (cut, n)):
+        s = Index(d, "f16")
+        s.upsert_device(0, x[lo:hi].contiguous())
+        ivf.build_ivf(s, 16, iters=3)
+        shards.append((lo, s))
+    keys = torch.cat([ivf.IvfShardEngine(s, nprobe=16).search_keys(q, k, lo) for lo, s in shards], dim=1)
+    _, d_got, r_got = whole.merge_keys(keys, k)
+    assert torch.equal(r_got, r_ref) and torch.equal(d_got, d_ref)
+    # and through ShardedSearcher (one rank: no collective), with a partial probe: global rows, sorted, mostly the true ones
+    lo, s = shards[1]
+    d1, r1 = ShardedSearcher(ivf.IvfShardEngine(s, nprobe=4), row_base=lo).search(q, k)
+    assert int(r1.min()) >= lo and bool((d1[:, 1:] >= d1[:, :-1]).all())
+    _, r_shard = s.search_tensors(q, k)
+    recall = (r1.unsqueeze(2) == (r_shard + lo).unsqueeze(1)).any(dim=2).float().mean().item()
+    assert recall >= 0.9
+    for ix in (whole, shards[0][1], shards[1][1]):
+        ix.close()
