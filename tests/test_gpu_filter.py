@@ -351,3 +351,40 @@ def test_search_async_pipelines_batches(Index, torch):
         d, r = h.result()
         assert torch.equal(r, r_ref) and torch.equal(d, d_ref)
     ix.close()
+
+
+def test_concurrent_host_threads_search_one_index(Index, torch):
+    """The service shares one store between request handlers (metrics_controller.py:22-38): several host threads may
+    search one index at once, on the default stream or on streams of their own."""
+    import threading
+
+    rng = np.random.default_rng(79)
+    raw = rng.standard_normal((40_000, 192)).astype(np.float32)
+    ix = Index(192)
+    ix.upsert(np.arange(raw.shape[0], dtype=np.int64), raw)
+    qs = [torch.from_numpy(rng.standard_normal((b, 192)).astype(np.float32)).cuda() for b in (1, 17, 64, 200)]
+    ref = [ix.search_tensors(q, 10) for q in qs]
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(i, own_stream):
+        try:
+            s = torch.cuda.Stream() if own_stream else torch.cuda.current_stream()
+            with torch.cuda.stream(s):
+                for _ in range(25):
+                    d, r = ix.search_tensors(qs[i], 10)
+                    s.synchronize()
+                    if not (torch.equal(r, ref[i][1]) and torch.equal(d, ref[i][0])):
+                        errors.append(f"thread {i} own_stream={own_stream}: wrong result")
+                        return
+        except Exception as e:  # noqa: BLE001
+            errors.append(f"thread {i}: {e!r}")
+
+    for own_stream in (False, True):
+        threads = [threading.Thread(target=worker, args=(i, own_stream)) for i in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    assert not errors, errors
+    ix.close()
