@@ -6,6 +6,8 @@
 //
 //   normalize_rows_kernel   ingest + query prep: c <- c/|c| (canonical sum of squares, IEEE sqrt/div),
 //                           writes the stored row AND its bf16 shadow in MFMA-fragment order
+//   prep_queries_kernel     one launch per batch of <= 256 queries: normalise, pack the MFMA fragments,
+//                           clear the pass's control block
 //   scan_topk_kernel        exact streaming scan (small batches, fallback): one wave owns 4 rows per
 //                           step, 16-B/lane coalesced loads, fmaf chains in canonical order,
 //                           wave-distributed top-k lists

@@ -161,7 +161,8 @@ int codd_knn_ivf_search(codd_knn_index* index, const float* dev_queries, int B, 
  *            "filter_min_batch" (9), "filter_min_rows" (1: batches >= filter_min_batch always
  *            filter when the corpus has >= 2k sample tiles), "filter_min_rows_small" (100000:
  *            smaller batches filter when rows * B reaches it): when the filter path is taken;
- *            "sample_div" (40: about 1/40 of the tiles set the per-query thresholds), "sample_tiles"
+ *            "sample_div" (40: about 1/40 of the tiles set the per-query thresholds, never
+ *            fewer than one tile per CU once the corpus has two rounds of tiles), "sample_tiles"
  *            (4096: upper bound on that number), "hit_cap" (per-query
  *            candidate capacity; overflow falls back to the exact scan);
  *            "profile" = N keeps N (start, stop) HIP-event pairs, one per heavy-kernel launch,
