@@ -285,8 +285,8 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const void* __restrict__
 // shard partials, and (m == k) to unpack final keys.
 // ---------------------------------------------------------------------------------------------
 template <int SLOTS>
-__global__ __launch_bounds__(256) void merge_keys_kernel(const u64* __restrict__ in, int64_t m, int64_t in_stride, int k,
-                                                         u64* __restrict__ out_keys, float* __restrict__ out_dist,
+__global__ __launch_bounds__(256) void merge_keys_kernel(const u64* __restrict__ in, int64_t m, int64_t in_stride, int64_t seg_len,
+                                                         int64_t seg_stride, int k, u64* __restrict__ out_keys, float* __restrict__ out_dist,
                                                          int64_t* __restrict__ out_rows, const unsigned* __restrict__ out_list,
                                                          const unsigned* __restrict__ count_ptr,
                                                          unsigned long long* __restrict__ count_total) {
@@ -304,7 +304,9 @@ __global__ __launch_bounds__(256) void merge_keys_kernel(const u64* __restrict__
     L.init();
     for (int64_t i0 = (int64_t)wave * kWave; i0 < m; i0 += 256) {
         const int64_t i = i0 + lane;
-        const u64 cand = i < m ? src[i] : 0ull;
+        // a query's m keys are m / seg_len runs of seg_len keys, seg_stride apart (one run when seg_len == m;
+        // one run per shard when the input is an all_gather of [B][k] partials)
+        const u64 cand = i < m ? src[(i / seg_len) * seg_stride + (i % seg_len)] : 0ull;
         L.offer_lanes(cand, k, lane);
     }
     __shared__ u64 lds[4 * SLOTS * kWave];
@@ -758,11 +760,14 @@ int launch_scan_nb(int nb, int niter, int slots, dim3 grid, hipStream_t st, cons
 
 int launch_merge(const u64* in, int B, int64_t m, int64_t in_stride, int k, u64* out_keys, float* out_dist, int64_t* out_rows,
                  hipStream_t st, const unsigned* out_list = nullptr, const unsigned* count_ptr = nullptr,
-                 unsigned long long* count_total = nullptr) {
+                 unsigned long long* count_total = nullptr, int64_t seg_len = 0, int64_t seg_stride = 0) {
+    if (seg_len <= 0) seg_len = m > 0 ? m : 1;
     if (k <= 64)
-        hipLaunchKernelGGL(merge_keys_kernel<1>, dim3(B), dim3(256), 0, st, in, m, in_stride, k, out_keys, out_dist, out_rows, out_list, count_ptr, count_total);
+        hipLaunchKernelGGL(merge_keys_kernel<1>, dim3(B), dim3(256), 0, st, in, m, in_stride, seg_len, seg_stride, k, out_keys, out_dist, out_rows,
+                           out_list, count_ptr, count_total);
     else
-        hipLaunchKernelGGL(merge_keys_kernel<2>, dim3(B), dim3(256), 0, st, in, m, in_stride, k, out_keys, out_dist, out_rows, out_list, count_ptr, count_total);
+        hipLaunchKernelGGL(merge_keys_kernel<2>, dim3(B), dim3(256), 0, st, in, m, in_stride, seg_len, seg_stride, k, out_keys, out_dist, out_rows,
+                           out_list, count_ptr, count_total);
     HIP_TRY(hipGetLastError());
     return CODD_KNN_OK;
 }
@@ -1271,6 +1276,14 @@ int codd_knn_merge_keys(int device, const uint64_t* dev_keys_in, int B, int m, i
     if (!dev_keys_in || B < 1 || m < 1 || k < 1 || k > CODD_KNN_MAX_K) return fail(CODD_KNN_EINVAL, "bad merge arguments%s");
     DeviceGuard guard(device);
     return launch_merge((const u64*)dev_keys_in, B, m, m, k, (u64*)dev_keys_out, dev_dist, dev_rows, (hipStream_t)stream);
+}
+
+int codd_knn_merge_shards(int device, const uint64_t* dev_keys_in, int G, int B, int k_in, int k, uint64_t* dev_keys_out, float* dev_dist,
+                          int64_t* dev_rows, void* stream) {
+    if (!dev_keys_in || G < 1 || B < 1 || k_in < 1 || k < 1 || k > CODD_KNN_MAX_K) return fail(CODD_KNN_EINVAL, "bad merge arguments%s");
+    DeviceGuard guard(device);
+    return launch_merge((const u64*)dev_keys_in, B, (int64_t)G * k_in, k_in, k, (u64*)dev_keys_out, dev_dist, dev_rows, (hipStream_t)stream, nullptr,
+                        nullptr, nullptr, k_in, (int64_t)B * k_in);
 }
 
 int codd_knn_approx_scores(codd_knn_index* ix, const float* dev_queries, int B, float* dev_scores, void* stream) {

@@ -201,3 +201,25 @@ def merge_keys(keys, k: int, device=None):
         "codd_knn_merge_keys",
     )
     return out_keys, dist, rows
+
+
+def merge_shards(gathered, world_size: int, k: int, device=None):
+    """codd_knn_merge_shards on the [G*B, k_in] int64 CUDA tensor an all_gather of the ranks' [B, k_in] keys delivers."""
+    torch = _torch()
+    lib = native.load()
+    if not (isinstance(gathered, torch.Tensor) and gathered.is_cuda and gathered.dtype == torch.int64 and gathered.dim() == 2
+            and gathered.shape[0] % world_size == 0):
+        raise ValueError("merge_shards wants a [G*B, k_in] int64 CUDA tensor")
+    gathered = gathered.contiguous()
+    dev = gathered.device if device is None else torch.device(device)
+    B, k_in = gathered.shape[0] // world_size, gathered.shape[1]
+    out_keys = torch.empty((B, k), dtype=torch.int64, device=dev)
+    dist = torch.empty((B, k), dtype=torch.float32, device=dev)
+    rows = torch.empty((B, k), dtype=torch.int64, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    native.check(
+        lib.codd_knn_merge_shards(dev.index or 0, gathered.data_ptr(), int(world_size), B, k_in, int(k), out_keys.data_ptr(), dist.data_ptr(),
+                                  rows.data_ptr(), stream),
+        "codd_knn_merge_shards",
+    )
+    return out_keys, dist, rows

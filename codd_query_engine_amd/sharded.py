@@ -67,10 +67,13 @@ class ShardedSearcher:
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._merge_gathered = None  # [G*B,k] as gathered -> results, without a transpose pass (HIP engines only)
         if merge is None:
             from .knn_index import merge_keys as hip_merge
+            from .knn_index import merge_shards as hip_merge_shards
 
             merge = hip_merge
+            self._merge_gathered = hip_merge_shards
         self._merge = merge
         self._streams: list = []
         self._turn = 0
@@ -114,6 +117,9 @@ class ShardedSearcher:
         # rank-major concatenation along dim 0 (the layout both RCCL and gloo accept)
         gathered = torch.empty((self.world_size * B, k), dtype=torch.int64, device=local.device)
         dist.all_gather_into_tensor(gathered, local.contiguous(), group=self.group)
+        if self._merge_gathered is not None:
+            _, d, r = self._merge_gathered(gathered, self.world_size, k)
+            return d, r
         merged_in = gathered.view(self.world_size, B, k).permute(1, 0, 2).reshape(B, self.world_size * k).contiguous()
         _, d, r = self._merge(merged_in, k)
         return d, r

@@ -127,6 +127,13 @@ int codd_knn_merge_keys(int device, const uint64_t* dev_keys_in, int B, int m, i
                         uint64_t* dev_keys_out, float* dev_dist, int64_t* dev_rows, void* stream);
 
 /*
+ * The same merge straight from the buffer an all_gather of the ranks' [B][k_in] partials delivers:
+ * dev_keys_in[(g * B + q) * k_in + j], g < G.  No transpose pass in between.
+ */
+int codd_knn_merge_shards(int device, const uint64_t* dev_keys_in, int G, int B, int k_in, int k,
+                          uint64_t* dev_keys_out, float* dev_dist, int64_t* dev_rows, void* stream);
+
+/*
  * The raw approximate (bf16 MFMA) scores of B <= 256 queries against every stored row:
  * dev_scores[q * count + row], q < 256 (rows of padding queries are zero).  Used by the IVF build
  * (row -> nearest centroid) and by tests that check the MFMA operand layouts in isolation.

@@ -44,6 +44,7 @@ def test_error_codes_without_a_device():
     assert lib.codd_knn_count(None, ctypes.byref(out)) == -22
     assert lib.codd_knn_search(None, None, 1, 1, None, None, None) == -22
     assert lib.codd_knn_merge_keys(0, None, 1, 1, 1, None, None, None, None) == -22
+    assert lib.codd_knn_merge_shards(0, None, 1, 1, 1, 1, None, None, None, None) == -22
     with pytest.raises(native.NativeLibraryError):
         native.check(-22, "demo")
 

@@ -148,6 +148,13 @@ def test_search_keys_and_merge_equal_whole_index(Index, torch):
     k_ref = o.search_keys(rows_ref, "f32", o.normalize_rows(q), 10)
     merged_keys = s0.merge_keys(keys, 10)[0].cpu().numpy().view(np.uint64)
     assert np.array_equal(merged_keys, k_ref)
+    # the same merge straight from the layout an all_gather delivers ([G*B, k], rank-major)
+    from codd_query_engine_amd.knn_index import merge_shards
+
+    gathered = torch.cat([s0.search_keys(q, 10, 0), s1.search_keys(q, 10, cut)], dim=0)
+    mk, d2, i2 = merge_shards(gathered, 2, 10)
+    assert np.array_equal(i2.cpu().numpy(), i_ref) and np.array_equal(d2.cpu().numpy(), d_ref)
+    assert np.array_equal(mk.cpu().numpy().view(np.uint64), k_ref)
     for ix in (whole, s0, s1):
         ix.close()
 
