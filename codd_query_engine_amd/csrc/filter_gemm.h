@@ -667,6 +667,16 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
     }
     const u64* my = hits + (int64_t)q * cap_q;
 
+    // the query's fragments for the exact re-scoring: requested first, so the round trip overlaps step 1
+    const int nchunks = dpad / E;
+    float qf[NITER][E];
+#pragma unroll
+    for (int it = 0; it < NITER; ++it) {
+        const int j = lane + kWave * it;
+#pragma unroll
+        for (int e = 0; e < E; ++e) qf[it][e] = j < nchunks ? qn[(int64_t)q * dpad + (int64_t)j * E + e] : 0.0f;
+    }
+
     // 1. k-th largest approximate key
     WaveTopK<SLOTS> L;
     L.init();
@@ -690,14 +700,6 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
     __syncthreads();
     const float lo = lds_lo;
 
-    const int nchunks = dpad / E;
-    float qf[NITER][E];
-#pragma unroll
-    for (int it = 0; it < NITER; ++it) {
-        const int j = lane + kWave * it;
-#pragma unroll
-        for (int e = 0; e < E; ++e) qf[it][e] = j < nchunks ? qn[(int64_t)q * dpad + (int64_t)j * E + e] : 0.0f;
-    }
     const uint4* base = reinterpret_cast<const uint4*>(rows_);
     WaveTopK<SLOTS> X;
     X.init();
