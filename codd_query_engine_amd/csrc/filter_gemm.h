@@ -141,6 +141,9 @@ constexpr int kHitCntStride = CODD_HITCNT_STRIDE;
 #ifndef CODD_RING
 #define CODD_RING 3
 #endif
+#ifndef CODD_STAGGER
+#define CODD_STAGGER 0  // 1: waves 4..7 run their MFMA halves half a K-step behind waves 0..3 (one barrier per K-step)
+#endif
 #ifndef CODD_QDEPTH
 #define CODD_QDEPTH 1   // 2: the query slice of step t+3 is requested during step t (one step more for the L2 round trip), 16 more VGPRs
 #endif
@@ -392,210 +395,294 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
     // for its whole cluster while the other loads/stages, which staggers them by half a step
     if (__builtin_amdgcn_readfirstlane(tid) >= kFilterThreads / 2) __builtin_amdgcn_s_setprio(CODD_STATIC_PRIO);
 #endif
-    int64_t c_u = first_u;  // compute cursor
-    int c_s = 0;
-    // T is walked in whole rings: the (at most kRing-1) padding steps past T recompute the last slice
-    // into accumulators nobody reads (`live` gates every side effect), which keeps the loop free of
-    // early exits and lets every load stay unconditional
-    for (int t0 = 0; t0 < T; t0 += kUnroll) {
-        // one K-step; IU (position inside the unrolled body) is a compile-time constant, so every register buffer
-        // (corpus ring slot, query staging buffer) is chosen by the front end, not by an optimisation pass
-        auto k_step = [&](auto IU) __attribute__((always_inline)) {
-            constexpr int iu = decltype(IU)::value;
-            constexpr int i = iu % kRing;
-            const int t = t0 + iu;
-            const bool live = t < T;
-            const int stage = t / kQS, sub = t % kQS;
-            // query slice of step t+kQS: issue now, write to LDS after the MFMAs
-            {
-                const uint4* src = qfrag + (int64_t)q_s * kStagePieces + stid;
-                if (!CODD_EXP_NO_QSTAGE) {
-#pragma unroll
-                    for (int j = 0; j < kQPn; ++j) (iu % kQD ? qreg1 : qreg0)[j] = reinterpret_cast<const q4u*>(src)[j * kFilterThreads];
-                }
-                q_s = q_s + 1 == nsteps ? 0 : q_s + 1;
-            }
-            // corpus fragments for step t+2 AFTER the query loads: vmcnt retires in order, so the
-            // end-of-step wait for the (L2-served) query slice must not sit behind these HBM loads
-            load_a(ring[(i + kPrefetch) % kRing]);
-            const uint4* qs = ldsQ + ((stage & 1) * kQS + sub) * kStagePieces + lane + qoff;  // qoff: this wave's query share
-#if CODD_MFMA_PRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
-            constexpr int kNqbRun = (CODD_EXP_NB < NBQ ? CODD_EXP_NB : NBQ) * kQBper32 / kQSplit;
-#pragma unroll
-            for (int ks = 0; ks < kKS; ++ks) {
-#pragma unroll
-                for (int qb = 0; qb < kNqbRun; ++qb) {
-                    const bf16x8 b = CODD_EXP_NO_LDSREAD ? __builtin_bit_cast(bf16x8, ring[i][0][(ks + qb) & 3])
-                                                         : __builtin_bit_cast(bf16x8, qs[b_piece(qb, ks) * 64]);
-#pragma unroll
-                    for (int rs = 0; rs < kRS; ++rs) {
-                        // row block rs lives in 32-row block rs / (32/kMB), sub-block rs % (32/kMB)
-                        const bf16x8 a = __builtin_bit_cast(bf16x8, ring[i][rs / kQBper32][a_piece(rs % kQBper32, ks)]);
-#if CODD_MFMA16 && CODD_SHADOW_F16
-                        acc[rs][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[rs][qb], 0, 0, 0);
-#elif CODD_MFMA16
-                        acc[rs][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[rs][qb], 0, 0, 0);
-#elif CODD_SHADOW_F16
-                        acc[rs][qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[rs][qb], 0, 0, 0);
-#else
-                        acc[rs][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[rs][qb], 0, 0, 0);
-#endif
-                    }
-                }
-            }
-#if CODD_MFMA_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-#if CODD_PIN_SCHEDULE && !CODD_EXP_NO_LDSREAD
-            // pin the step's shape: all 8 global loads (4 query, 4 corpus) first so they fly under the
-            // MFMAs; at most a few query fragments live (4 LDS reads up front, then one per MFMA);
-            // the LDS writes of the next query slice last
-            __builtin_amdgcn_sched_group_barrier(0x020, 4 * kRB + (CODD_EXP_NO_QSTAGE ? 0 : kQPn), 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-            for (int g = 0; g < kKS * kNqbRun - 4; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, kRS, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * kRS, 0);
-            if (!CODD_EXP_NO_QSTAGE) __builtin_amdgcn_sched_group_barrier(0x200, kQPn, 0);
-#endif
-            {
-                uint4* dstq = ldsQ + (((stage + 1) & 1) * kQS + sub) * kStagePieces + stid;
-                if (!CODD_EXP_NO_QSTAGE) {
-#pragma unroll
-                    for (int j = 0; j < kQPn; ++j) reinterpret_cast<q4u*>(dstq)[j * kFilterThreads] = ((iu + kQD - 1) % kQD ? qreg1 : qreg0)[j];
-                }
-            }
+    // ------------------------------------------------------------------------------------------------------------
+    // Main loop.  An *interval* is the time between two workgroup barriers and covers one 64-wide K-step of work per
+    // wave.  Query staging (loads of slice t+kQS at the top, LDS writes at the bottom) is tied to the interval for
+    // every wave.  With CODD_STAGGER the second-dispatched half of the workgroup (waves 4..7 = the SIMD partners of
+    // waves 0..3) runs its MFMA work half a K-step late: in interval t it multiplies the second K-half of step t-1,
+    // then the first K-half of step t, and issues its corpus loads between the two.  The two waves of a SIMD then reach
+    // their loads, waits and epilogues at different times instead of in lockstep (MI355X_MICROARCH.md, "two waves per
+    // SIMD", item 9).  Slice hazards with 4 LDS slices: interval t reads slices t-1 and t and writes slice t+2.
+    // ------------------------------------------------------------------------------------------------------------
+    constexpr int kLag = (CODD_STAGGER && MODE == MODE_FILTER && kKS == 2) ? 1 : 0;
+    constexpr bool kBarrierEveryStep = kLag == 1;
+    constexpr int kNqbRun = (CODD_EXP_NB < NBQ ? CODD_EXP_NB : NBQ) * kQBper32 / kQSplit;
+    const int TI = T + kLag;  // intervals
 
-            const bool tile_end = live && c_s == nsteps - 1;
-            if (tile_end && !CODD_NO_EPILOGUE) {
-                // ---- tile epilogue ----
-                const int64_t tile = c_u * tile_stride;
-                const bool ragged = (tile + 1) * kTileRows > n;
+    // MFMAs of K-halves [KS0, KS1) of the step whose corpus fragments sit in ring slot SLOT and whose query slice is at qs
+    auto mfma_part = [&](auto SLOT, auto KS0, auto KS1, const uint4* qs) __attribute__((always_inline)) {
+        constexpr int slot = decltype(SLOT)::value;
+#pragma unroll
+        for (int ks = decltype(KS0)::value; ks < decltype(KS1)::value; ++ks) {
+#pragma unroll
+            for (int qb = 0; qb < kNqbRun; ++qb) {
+                const bf16x8 b = CODD_EXP_NO_LDSREAD ? __builtin_bit_cast(bf16x8, ring[slot][0][(ks + qb) & 3])
+                                                     : __builtin_bit_cast(bf16x8, qs[b_piece(qb, ks) * 64]);
 #pragma unroll
                 for (int rs = 0; rs < kRS; ++rs) {
-                    const int64_t row0 = tile * kTileRows + wr * (32 * kRB) + rs * kMB;  // + acc_row(r, lane)
-                    if (MODE == MODE_FILTER) {
+                    // row block rs lives in 32-row block rs / (32/kMB), sub-block rs % (32/kMB)
+                    const bf16x8 a = __builtin_bit_cast(bf16x8, ring[slot][rs / kQBper32][a_piece(rs % kQBper32, ks)]);
+#if CODD_MFMA16 && CODD_SHADOW_F16
+                    acc[rs][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[rs][qb], 0, 0, 0);
+#elif CODD_MFMA16
+                    acc[rs][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[rs][qb], 0, 0, 0);
+#elif CODD_SHADOW_F16
+                    acc[rs][qb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[rs][qb], 0, 0, 0);
+#else
+                    acc[rs][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[rs][qb], 0, 0, 0);
+#endif
+                }
+            }
+        }
+    };
+    // threshold test / bucket maxima / dump of the finished tile cu (run-tile ordinal), then clear the accumulators
+    auto tile_epilogue = [&](int64_t cu) __attribute__((always_inline)) {
+        if (!CODD_NO_EPILOGUE) {
+            const int64_t tile = cu * tile_stride;
+            const bool ragged = (tile + 1) * kTileRows > n;
 #pragma unroll
-                        for (int qb = 0; qb < NQB; ++qb) {
-                            const float th = CODD_EXP_NO_HITS ? INFINITY : __uint_as_float(lds_w[qbase + qb * kMB]);
-                            float m = acc[rs][qb][0];
+            for (int rs = 0; rs < kRS; ++rs) {
+                const int64_t row0 = tile * kTileRows + wr * (32 * kRB) + rs * kMB;  // + acc_row(r, lane)
+                if (MODE == MODE_FILTER) {
 #pragma unroll
-                            for (int r = 1; r < kAccRegs; ++r) m = fmaxf(m, acc[rs][qb][r]);
-                            if (__any(m >= th)) {
+                    for (int qb = 0; qb < NQB; ++qb) {
+                        const float th = CODD_EXP_NO_HITS ? INFINITY : __uint_as_float(lds_w[qbase + qb * kMB]);
+                        float m = acc[rs][qb][0];
+#pragma unroll
+                        for (int r = 1; r < kAccRegs; ++r) m = fmaxf(m, acc[rs][qb][r]);
+                        if (__any(m >= th)) {
 #if CODD_BALLOT_HITS
-                                // one LDS atomic per block that has hits (lane 0 reserves the block's slots, every
-                                // hit lane finds its own from the ballots) instead of one contended atomic per register
-                                unsigned tot = 0;
+                            // one LDS atomic per block that has hits (lane 0 reserves the block's slots, every
+                            // hit lane finds its own from the ballots) instead of one contended atomic per register
+                            unsigned tot = 0;
 #pragma unroll
-                                for (int r = 0; r < kAccRegs; ++r)
-                                    tot += (unsigned)__popcll(__ballot(acc[rs][qb][r] >= th && row0 + acc_row(r, lane) < n));
-                                unsigned base = 0;
-                                if (lane == 0) base = atomicAdd(&lds_w[256], tot);
-                                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                            for (int r = 0; r < kAccRegs; ++r)
+                                tot += (unsigned)__popcll(__ballot(acc[rs][qb][r] >= th && row0 + acc_row(r, lane) < n));
+                            unsigned base = 0;
+                            if (lane == 0) base = atomicAdd(&lds_w[256], tot);
+                            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
 #pragma unroll
-                                for (int r = 0; r < kAccRegs; ++r) {
-                                    const bool hit = acc[rs][qb][r] >= th && row0 + acc_row(r, lane) < n;
-                                    const unsigned long long mk = __ballot(hit);
-                                    if (hit) {
-                                        const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                                        if (slot < (unsigned)kHitCap) {
-                                            lds_hits[slot * 3 + 0] = __float_as_uint(acc[rs][qb][r]);
-                                            lds_hits[slot * 3 + 1] = (unsigned)(row0 + acc_row(r, lane));
-                                            lds_hits[slot * 3 + 2] = (unsigned)(qbase + qb * kMB);
-                                        } else {
-                                            atomicOr(&hit_cnt[(qbase + qb * kMB) * kHitCntStride], 0x80000000u);  // see below
-                                        }
+                            for (int r = 0; r < kAccRegs; ++r) {
+                                const bool hit = acc[rs][qb][r] >= th && row0 + acc_row(r, lane) < n;
+                                const unsigned long long mk = __ballot(hit);
+                                if (hit) {
+                                    const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                                    if (slot < (unsigned)kHitCap) {
+                                        lds_hits[slot * 3 + 0] = __float_as_uint(acc[rs][qb][r]);
+                                        lds_hits[slot * 3 + 1] = (unsigned)(row0 + acc_row(r, lane));
+                                        lds_hits[slot * 3 + 2] = (unsigned)(qbase + qb * kMB);
+                                    } else {
+                                        atomicOr(&hit_cnt[(qbase + qb * kMB) * kHitCntStride], 0x80000000u);  // see below
                                     }
-                                    base += (unsigned)__popcll(mk);
                                 }
+                                base += (unsigned)__popcll(mk);
+                            }
 #else
 #pragma unroll
-                                for (int r = 0; r < kAccRegs; ++r) {
-                                    const float v = acc[rs][qb][r];
-                                    const int64_t row = row0 + acc_row(r, lane);
-                                    if (v >= th && row < n) {
-                                        const unsigned slot = atomicAdd(&lds_w[256], 1u);
-                                        if (slot < (unsigned)kHitCap) {
-                                            lds_hits[slot * 3 + 0] = __float_as_uint(v);
-                                            lds_hits[slot * 3 + 1] = (unsigned)row;
-                                            lds_hits[slot * 3 + 2] = (unsigned)(qbase + qb * kMB);
-                                        } else {
-                                            // workgroup list full (> kHitCap/2 hits inside ONE tile: a dense cluster
-                                            // that many queries point at): this query's candidates are incomplete ->
-                                            // poison its counter (top bit: reads as "> cap", can never wrap) so that
-                                            // finalize queues exactly this query for the exact scan.  (Appending to the
-                                            // global list from here instead was measured 5 % slower on the whole kernel:
-                                            // the extra address arithmetic / call in the epilogue hurts the MFMA loop's
-                                            // register allocation.)
-                                            atomicOr(&hit_cnt[(qbase + qb * kMB) * kHitCntStride], 0x80000000u);
-                                        }
+                            for (int r = 0; r < kAccRegs; ++r) {
+                                const float v = acc[rs][qb][r];
+                                const int64_t row = row0 + acc_row(r, lane);
+                                if (v >= th && row < n) {
+                                    const unsigned slot = atomicAdd(&lds_w[256], 1u);
+                                    if (slot < (unsigned)kHitCap) {
+                                        lds_hits[slot * 3 + 0] = __float_as_uint(v);
+                                        lds_hits[slot * 3 + 1] = (unsigned)row;
+                                        lds_hits[slot * 3 + 2] = (unsigned)(qbase + qb * kMB);
+                                    } else {
+                                        // workgroup list full (> kHitCap/2 hits inside ONE tile: a dense cluster
+                                        // that many queries point at): this query's candidates are incomplete ->
+                                        // poison its counter (top bit: reads as "> cap", can never wrap) so that
+                                        // finalize queues exactly this query for the exact scan.  (Appending to the
+                                        // global list from here instead was measured 5 % slower on the whole kernel:
+                                        // the extra address arithmetic / call in the epilogue hurts the MFMA loop's
+                                        // register allocation.)
+                                        atomicOr(&hit_cnt[(qbase + qb * kMB) * kHitCntStride], 0x80000000u);
                                     }
                                 }
+                            }
 #endif
-                            }
                         }
-                    } else if (MODE == MODE_SAMPLE) {
-#pragma unroll
-                        for (int qb = 0; qb < NQB; ++qb) {
-                            float m = -INFINITY;
-#pragma unroll
-                            for (int r = 0; r < kAccRegs; ++r) {
-                                const int64_t row = row0 + acc_row(r, lane);
-                                const float v = (!ragged || row < n) ? acc[rs][qb][r] : -INFINITY;
-                                m = fmaxf(m, v);
-                            }
-                            atomicMax(&lds_w[qbase + qb * kMB], ord_f32(m));
-                        }
-                    } else {
-#pragma unroll
-                        for (int qb = 0; qb < NQB; ++qb)
-#pragma unroll
-                            for (int r = 0; r < kAccRegs; ++r) {
-                                const int64_t row = row0 + acc_row(r, lane);
-                                if (row < n) dump[(int64_t)(qbase + qb * kMB) * n + row] = acc[rs][qb][r];
-                            }
                     }
-                }  // rs
-            }
-            if (tile_end) {
+                } else if (MODE == MODE_SAMPLE) {
 #pragma unroll
-                for (int rs = 0; rs < kRS; ++rs)
+                    for (int qb = 0; qb < NQB; ++qb) {
+                        float m = -INFINITY;
+#pragma unroll
+                        for (int r = 0; r < kAccRegs; ++r) {
+                            const int64_t row = row0 + acc_row(r, lane);
+                            const float v = (!ragged || row < n) ? acc[rs][qb][r] : -INFINITY;
+                            m = fmaxf(m, v);
+                        }
+                        atomicMax(&lds_w[qbase + qb * kMB], ord_f32(m));
+                    }
+                } else {
 #pragma unroll
                     for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
-                        for (int r = 0; r < kAccRegs; ++r) acc[rs][qb][r] = 0.0f;
-            }
-            // stage boundary: the other stage is complete and this one is free to be overwritten.
-            // A tile end synchronises too (its bookkeeping below needs every wave's epilogue done).
-            if ((sub == kQS - 1 && !CODD_EXP_NO_BARRIER) || tile_end) __syncthreads();
-            if (MODE == MODE_FILTER && tile_end) {
-                // empty the workgroup's hit list once it is half full
-                const unsigned cnt = lds_w[256];
-                __syncthreads();  // everyone has read cnt before the next epilogue can move it
-                if (cnt > (unsigned)(CODD_FLUSH_AT)) {
-                    flush_hits(lds_hits, cnt < (unsigned)kHitCap ? cnt : (unsigned)kHitCap, tid, hits, hit_cnt, cap_q);
-                    __syncthreads();
-                    if (tid == 0) lds_w[256] = 0u;
+                        for (int r = 0; r < kAccRegs; ++r) {
+                            const int64_t row = row0 + acc_row(r, lane);
+                            if (row < n) dump[(int64_t)(qbase + qb * kMB) * n + row] = acc[rs][qb][r];
+                        }
+                }
+            }  // rs
+        }
+#pragma unroll
+        for (int rs = 0; rs < kRS; ++rs)
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                for (int r = 0; r < kAccRegs; ++r) acc[rs][qb][r] = 0.0f;
+    };
+    auto slice_ptr = [&](int step) -> const uint4* {  // LDS address of the query slice of a step (4 slices, cyclic)
+        return ldsQ + ((step + 4) & (2 * kQS - 1)) * kStagePieces + lane + qoff;
+    };
+    static_assert(kQS == 2 || !kLag, "the staggered schedule is written for 4 LDS slices");
+
+    int64_t c_u = first_u;  // compute cursor: the step a wave finishes in this interval (a lagging wave: step t-1)
+    int c_s = 0;
+    int64_t w_u = first_u;  // workgroup cursor: the step ALL waves have finished by the end of this interval
+    int w_s = 0;
+    // TI is walked in whole unrolled bodies: the padding intervals past it recompute the last slice into accumulators
+    // nobody reads (`live` gates every side effect), which keeps the loop free of early exits and lets every load stay
+    // unconditional
+    auto run = [&](auto LAG) __attribute__((always_inline)) {
+        constexpr int lag = decltype(LAG)::value;
+        for (int t0 = 0; t0 < TI; t0 += kUnroll) {
+            // one interval; IU (position inside the unrolled body) is a compile-time constant, so every register
+            // buffer (corpus ring slot, query staging buffer) is chosen by the front end, not by an optimisation pass
+            auto k_step = [&](auto IU) __attribute__((always_inline)) {
+                constexpr int iu = decltype(IU)::value;
+                constexpr int i = iu % kRing;
+                const int t = t0 + iu;
+                const int stage = t / kQS, sub = t % kQS;
+                // query slice of step t+kQS: issue now, write to LDS at the end of the interval
+                {
+                    const uint4* src = qfrag + (int64_t)q_s * kStagePieces + stid;
+                    if (!CODD_EXP_NO_QSTAGE) {
+#pragma unroll
+                        for (int j = 0; j < kQPn; ++j) (iu % kQD ? qreg1 : qreg0)[j] = reinterpret_cast<const q4u*>(src)[j * kFilterThreads];
+                    }
+                    q_s = q_s + 1 == nsteps ? 0 : q_s + 1;
+                }
+                if constexpr (lag == 0) {
+                    const bool live = t < T;
+                    // corpus fragments for step t+2 AFTER the query loads: vmcnt retires in order, so the
+                    // end-of-step wait for the (L2-served) query slice must not sit behind these HBM loads
+                    load_a(ring[(i + kPrefetch) % kRing]);
+#if CODD_MFMA_PRIO
+                    __builtin_amdgcn_s_setprio(1);
+#endif
+                    mfma_part(std::integral_constant<int, i>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, kKS>{}, slice_ptr(t));
+#if CODD_MFMA_PRIO
+                    __builtin_amdgcn_s_setprio(0);
+#endif
+#if CODD_PIN_SCHEDULE && !CODD_EXP_NO_LDSREAD
+                    // pin the step's shape: all 8 global loads (4 query, 4 corpus) first so they fly under the
+                    // MFMAs; at most a few query fragments live (4 LDS reads up front, then one per MFMA);
+                    // the LDS writes of the next query slice last
+                    __builtin_amdgcn_sched_group_barrier(0x020, 4 * kRB + (CODD_EXP_NO_QSTAGE ? 0 : kQPn), 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                    for (int g = 0; g < kKS * kNqbRun - 4; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, kRS, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * kRS, 0);
+                    if (!CODD_EXP_NO_QSTAGE) __builtin_amdgcn_sched_group_barrier(0x200, kQPn, 0);
+#endif
+                    {
+                        uint4* dstq = ldsQ + (((stage + 1) & 1) * kQS + sub) * kStagePieces + stid;
+                        if (!CODD_EXP_NO_QSTAGE) {
+#pragma unroll
+                            for (int j = 0; j < kQPn; ++j)
+                                reinterpret_cast<q4u*>(dstq)[j * kFilterThreads] = ((iu + kQD - 1) % kQD ? qreg1 : qreg0)[j];
+                        }
+                    }
+                    if (live && c_s == nsteps - 1) tile_epilogue(c_u);
+                    if (++c_s == nsteps) { c_s = 0; c_u += step_u; }
+                } else {
+                    // ---- lagging wave: second K-half of step t-1, epilogue, corpus loads, first K-half of step t ----
+                    const bool live_prev = t >= 1 && t - 1 < T;
+                    mfma_part(std::integral_constant<int, (i + kRing - 1) % kRing>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{},
+                              slice_ptr(t - 1));
+#if CODD_PIN_SCHEDULE && !CODD_EXP_NO_LDSREAD
+                    __builtin_amdgcn_sched_group_barrier(0x020, (CODD_EXP_NO_QSTAGE ? 0 : kQPn), 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                    for (int g = 0; g < kNqbRun - 4; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, kRS, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * kRS, 0);
+#endif
+                    if (t >= 1) {
+                        if (live_prev && c_s == nsteps - 1) tile_epilogue(c_u);
+                        if (++c_s == nsteps) { c_s = 0; c_u += step_u; }
+                    } else {
+                        // interval 0 multiplied nothing meaningful (there is no step -1): start from clean accumulators
+#pragma unroll
+                        for (int rs = 0; rs < kRS; ++rs)
+#pragma unroll
+                            for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                                for (int r = 0; r < kAccRegs; ++r) acc[rs][qb][r] = 0.0f;
+                    }
+                    load_a(ring[(i + kPrefetch) % kRing]);  // the slot the second half of step t-1 has just released
+                    mfma_part(std::integral_constant<int, i>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, slice_ptr(t));
+#if CODD_PIN_SCHEDULE && !CODD_EXP_NO_LDSREAD
+                    __builtin_amdgcn_sched_group_barrier(0x020, 4 * kRB, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                    for (int g = 0; g < kNqbRun - 4; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, kRS, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4 * kRS, 0);
+                    if (!CODD_EXP_NO_QSTAGE) __builtin_amdgcn_sched_group_barrier(0x200, kQPn, 0);
+#endif
+                    {
+                        uint4* dstq = ldsQ + (((stage + 1) & 1) * kQS + sub) * kStagePieces + stid;
+                        if (!CODD_EXP_NO_QSTAGE) {
+#pragma unroll
+                            for (int j = 0; j < kQPn; ++j)
+                                reinterpret_cast<q4u*>(dstq)[j * kFilterThreads] = ((iu + kQD - 1) % kQD ? qreg1 : qreg0)[j];
+                        }
+                    }
+                }
+
+                // ---- workgroup bookkeeping (identical in both programs: the barriers must pair up) ----
+                // the step every wave has finished by the end of this interval is t - kLag
+                const bool wg_tile_end = t >= kLag && t - kLag < T && w_s == nsteps - 1;
+                // stage boundary: the other stage is complete and this one is free to be overwritten.
+                // A tile end synchronises too (its bookkeeping below needs every wave's epilogue done).
+                if (kBarrierEveryStep || (sub == kQS - 1 && !CODD_EXP_NO_BARRIER) || wg_tile_end) __syncthreads();
+                if (MODE == MODE_FILTER && wg_tile_end) {
+                    // empty the workgroup's hit list once it is half full
+                    const unsigned cnt = lds_w[256];
+                    __syncthreads();  // everyone has read cnt before the next epilogue can move it
+                    if (cnt > (unsigned)(CODD_FLUSH_AT)) {
+                        flush_hits(lds_hits, cnt < (unsigned)kHitCap ? cnt : (unsigned)kHitCap, tid, hits, hit_cnt, cap_q);
+                        __syncthreads();
+                        if (tid == 0) lds_w[256] = 0u;
+                        __syncthreads();
+                    }
+                }
+                if (MODE == MODE_SAMPLE && wg_tile_end) {
+                    // all 8 waves have folded this tile into lds_w: publish, reset, and fence the reset
+                    // against the next tile's fold
+                    if (tid < 256) {
+                        bucket_max[(int64_t)tid * ntiles_run + w_u] = unord_f32(lds_w[tid]);  // [query][bucket]: select_thr reads rows
+                        lds_w[tid] = 0u;
+                    }
                     __syncthreads();
                 }
-            }
-            if (MODE == MODE_SAMPLE && tile_end) {
-                // all 8 waves have folded this tile into lds_w: publish, reset, and fence the reset
-                // against the next tile's fold
-                if (tid < 256) {
-                    bucket_max[(int64_t)tid * ntiles_run + c_u] = unord_f32(lds_w[tid]);  // [query][bucket]: select_thr reads rows
-                    lds_w[tid] = 0u;
-                }
-                __syncthreads();
-            }
-            if (++c_s == nsteps) { c_s = 0; c_u += step_u; }
-        };
-        static_for<kUnroll>(k_step);
-    }
+                if (t >= kLag && ++w_s == nsteps) { w_s = 0; w_u += step_u; }
+            };
+            static_for<kUnroll>(k_step);
+        }
+    };
+    if (kLag && __builtin_amdgcn_readfirstlane(wave) >= kFilterWaves / 2) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 0>{});
 
     if (MODE == MODE_FILTER) {
         __syncthreads();

@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "base": {},
-    "qd2": {"CODD_QDEPTH": 2},
+    "stagger": {"CODD_STAGGER": 1},
 }
 
 
