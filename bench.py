@@ -107,7 +107,30 @@ def cpu_baseline(ix, args, queries_cpu):
     o.search_fast_f32(rows, qn, args.k)
     dt = time.perf_counter() - t0
     qps_full = (nq * n / dt) / args.rows  # same work per row: scale the sample to the full corpus
+    # SURVEY.md §8(d) comparator 3: the same sample as one fp32 GEMM + topk on torch's CPU backend (all threads).  Not the
+    # canonical arithmetic (blocked summation order), so it is a speed comparator only, never a checker.
+    gemm = None
+    try:
+        import torch
+
+        rt, qt = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.float32)), torch.from_numpy(qn)
+        (qt @ rt[:4096].T).topk(args.k, dim=1)
+        t1 = time.perf_counter()
+        best = None
+        for c0 in range(0, n, 1_000_000):  # chunked: the [nq, n] score block never exists in full
+            sc, ix_ = (qt @ rt[c0 : c0 + 1_000_000].T).topk(min(args.k, rt[c0 : c0 + 1_000_000].shape[0]), dim=1)
+            cand = (sc, ix_ + c0)
+            if best is not None:
+                sc2, sel = torch.cat([best[0], cand[0]], 1).topk(args.k, dim=1)
+                cand = (sc2, torch.cat([best[1], cand[1]], 1).gather(1, sel))
+            best = cand
+        dt_g = time.perf_counter() - t1
+        gemm = {"value": (nq * n / dt_g) / args.rows, "unit": "queries/s", "threads": torch.get_num_threads(),
+                "what": "torch CPU: chunked Q @ C^T + topk on the same sample, scaled the same way"}
+    except Exception as e:  # noqa: BLE001
+        gemm = {"value": None, "what": f"failed: {e}"}
     return {
+        "also_torch_cpu_gemm_topk": gemm,
         "value": qps_full,
         "unit": "queries/s",
         "cores": o.num_threads(),
