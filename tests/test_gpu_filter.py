@@ -82,6 +82,8 @@ def test_mfma_scores_match_rounded_operand_reference(Index, n, d, B, dtype):
         (30_000, 64, 40, 10, "f32"),     # ONE K-step per tile (query stages wrap inside a stage)
         (30_000, 320, 40, 10, "f32"),    # odd number of K-steps (5): tiles end mid-stage
         (8_000, 2048, 24, 10, "bf16"),   # widest row (32 K-steps)
+        (30_000, 128, 1024, 10, "f32"),  # the ABI's largest batch: four query passes
+        (70_000, 256, 16, 128, "f32"),   # the ABI's largest k (needs 2k = 256 sample tiles)
     ],
 )
 def test_filter_path_is_exact(Index, n, d, B, k, dtype):
