@@ -351,6 +351,133 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restric
     if (lane == 0) ids[r] = (uint32_t)from;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// int8 shadow (small batches: half the bytes of the bf16 shadow).  Row r is stored as round(c_i / scale_r), scale_r =
+// max|c_i| / 127, in the same fragment order as the bf16 shadow with 16-element pieces and 128-element K-steps.  The
+// filter's error bound needs |c - c~| for the worst row: every wave folds its row's error norm into *eps_r (ordered bits).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float butterfly_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, kWave));
+    return v;
+}
+__device__ __forceinline__ uint32_t quantize4(const float (&v)[4], float inv_scale, float scale, float& err2) {
+    uint32_t packed = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float t = __builtin_rintf(v[e] * inv_scale);
+        t = fminf(fmaxf(t, -127.0f), 127.0f);
+        const float d = v[e] - t * scale;
+        err2 = __builtin_fmaf(d, d, err2);
+        packed |= ((uint32_t)(int)t & 0xffu) << (8 * e);
+    }
+    return packed;
+}
+template <int DT>
+__global__ __launch_bounds__(256) void shadow8_from_rows_kernel(const void* __restrict__ rows_, int64_t first, int64_t n, int dpad, int dpad8,
+                                                                uint32_t* __restrict__ shadow8, float* __restrict__ rscale,
+                                                                unsigned* __restrict__ eps_r_bits) {
+    const int lane = lane_id();
+    const int64_t r0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r0 >= n) return;
+    const int64_t row = first + r0;
+    const int nch = dpad >> 2, nch8 = dpad8 >> 2, nsteps8 = dpad8 >> 7;
+    float vmax = 0.0f;
+    for (int j = lane; j < nch; j += kWave) {
+        float v[4];
+        if (DT == DT_F32) {
+            const float4 x = reinterpret_cast<const float4*>(rows_)[row * (int64_t)nch + j];
+            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+        } else {
+            const uint2 x = reinterpret_cast<const uint2*>(rows_)[row * (int64_t)nch + j];
+            const uint16_t hb[4] = {(uint16_t)(x.x & 0xffffu), (uint16_t)(x.x >> 16), (uint16_t)(x.y & 0xffffu), (uint16_t)(x.y >> 16)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = DT == DT_BF16 ? __uint_as_float((uint32_t)hb[e] << 16) : f16_bits_to_f32(hb[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fabsf(v[e]));
+    }
+    vmax = butterfly_max(vmax);
+    const float scale = vmax > 0.0f ? vmax / 127.0f : 1.0f, inv_scale = 1.0f / scale;
+    float err2 = 0.0f;
+    for (int j = lane; j < nch8; j += kWave) {
+        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (j < nch) {
+            if (DT == DT_F32) {
+                const float4 x = reinterpret_cast<const float4*>(rows_)[row * (int64_t)nch + j];
+                v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+            } else {
+                const uint2 x = reinterpret_cast<const uint2*>(rows_)[row * (int64_t)nch + j];
+                const uint16_t hb[4] = {(uint16_t)(x.x & 0xffffu), (uint16_t)(x.x >> 16), (uint16_t)(x.y & 0xffffu), (uint16_t)(x.y >> 16)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = DT == DT_BF16 ? __uint_as_float((uint32_t)hb[e] << 16) : f16_bits_to_f32(hb[e]);
+            }
+        }
+        // elements [4j, 4j+4) = dword (j & 3) of the 16-byte piece c16 = j >> 2
+        shadow8[codd::shadow_piece_index(row, j >> 2, nsteps8) * 4 + (j & 3)] = quantize4(v, inv_scale, scale, err2);
+    }
+    err2 = butterfly_sum(err2);
+    if (lane == 0) {
+        rscale[row] = scale;
+        // inflated a little: the norm itself was accumulated in fp32
+        atomicMax(eps_r_bits, __float_as_uint(__builtin_sqrtf(err2) * 1.0001f + 1e-7f));  // non-negative floats order as their bits
+    }
+}
+
+// prep_queries_kernel for the int8 filter: qn as always; the query quantised like a row (qfrag8, scale in qmeta[q]);
+// qmeta[256 + q] = 2 * eps(q) with eps(q) = |q - q~| (1.01 + eps_r) + 1.001 eps_r + 2e-6 >= |<q~, c~> - <q, c>| for every
+// stored row c (|c| <= 1.004 whatever the storage type, |c - c~| <= eps_r, |q| <= 1 + 1e-6; the integer accumulation
+// is exact and the two scale multiplications cost < 4e-7)
+__global__ __launch_bounds__(256) void prep_queries8_kernel(const float* __restrict__ in, int B, int d, int dpad, int dpad8,
+                                                            float* __restrict__ qn, uint32_t* __restrict__ qfrag8, float* __restrict__ qmeta,
+                                                            const unsigned* __restrict__ eps_r_bits, unsigned* __restrict__ ctl, int ctl_words) {
+    const int lane = lane_id();
+    const int q = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    for (int i = (int)blockIdx.x * 256 + (int)threadIdx.x; i < ctl_words; i += (int)gridDim.x * 256) ctl[i] = 0u;
+    const int nch = dpad >> 2, nch8 = dpad8 >> 2;
+    if (q >= B) {
+        for (int j = lane; j < nch8; j += kWave) qfrag8[codd::qfrag_piece_index(q, j >> 2) * 4 + (j & 3)] = 0u;
+        if (lane == 0) { qmeta[q] = 0.0f; qmeta[256 + q] = 0.0f; }
+        return;
+    }
+    const float* x = in + (int64_t)q * d;
+    const float nrm = canonical_norm(x, d, nch, lane);
+    const bool zero_row = !(nrm > 0.0f) || !(nrm < INFINITY);
+    float vmax = 0.0f;
+    for (int j = lane; j < nch; j += kWave) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = j * 4 + e;
+            const float t = i < d ? x[i] : 0.0f;
+            v[e] = zero_row ? 0.0f : t / nrm;
+            vmax = fmaxf(vmax, fabsf(v[e]));
+        }
+        reinterpret_cast<float4*>(qn)[(int64_t)q * nch + j] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    vmax = butterfly_max(vmax);
+    const float scale = vmax > 0.0f ? vmax / 127.0f : 0.0f, inv_scale = vmax > 0.0f ? 127.0f / vmax : 0.0f;
+    float err2 = 0.0f;
+    for (int j = lane; j < nch8; j += kWave) {
+        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (j < nch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = j * 4 + e;
+                const float t = i < d ? x[i] : 0.0f;
+                v[e] = zero_row ? 0.0f : t / nrm;
+            }
+        }
+        qfrag8[codd::qfrag_piece_index(q, j >> 2) * 4 + (j & 3)] = quantize4(v, inv_scale, scale, err2);
+    }
+    err2 = butterfly_sum(err2);
+    if (lane == 0) {
+        const float eq = __builtin_sqrtf(err2) * 1.0001f + 1e-7f, er = __uint_as_float(*eps_r_bits);
+        qmeta[q] = scale;
+        qmeta[256 + q] = 2.0f * (eq * (1.01f + er) + 1.001f * er + 2e-6f);
+    }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void widen_rows_kernel(const void* __restrict__ rows_, int64_t first, int64_t n, int dim, int dpad,
                                                          float* __restrict__ out) {
@@ -484,6 +611,8 @@ struct WorkBufs {
     u64* hits = nullptr;       int64_t hits_cap = 0;      // [256][hit_cap_q]
     FilterCtl* ctl = nullptr;                              // device
     u64* fb_partial = nullptr; int64_t fb_partial_cap = 0; // [256][blocks][k] partials of the fallback scan
+    uint4* qfrag8 = nullptr;   int64_t qfrag8_cap = 0;    // int8 query fragments (pieces)
+    float* qmeta = nullptr;                                // [512]: query scales, 2*eps per query (int8 filter)
     u64* probe_keys = nullptr; int64_t probe_cap = 0;      // IVF: [B][nprobe] coarse keys
     u64* ivf_partial = nullptr; int64_t ivf_partial_cap = 0;
 };
@@ -522,6 +651,20 @@ struct codd_knn_index : WorkBufs {
 
     unsigned long long* dstats = nullptr;                  // device counters: hits, survivors, fallback queries
 
+    // int8 shadow for small batches (optional; rebuilt lazily from the stored rows when they have changed)
+    int shadow8_enabled = 1;
+    int shadow8_max_batch = 8;    // batches up to this size take the int8 filter (beyond, its candidate volume costs more than the bytes save)
+    int sample_div8 = 20;         // its thresholds come from a larger sample (the int8 slack is ~5x the bf16 one)
+    uint4* shadow8 = nullptr;
+    int64_t shadow8_rows = 0;     // rows the allocation covers (multiple of 256)
+    float* rscale = nullptr;      // [shadow8_rows]
+    unsigned* eps_r_bits = nullptr;  // device scalar: max row error norm (float bits)
+    int64_t shadow8_epoch = -1;
+    int64_t dirty_lo = 0, dirty_hi = 0;  // rows written since the int8 shadow was last brought up to date: [lo, hi)
+    hipStream_t shadow8_stream = nullptr;  // the stream the last rebuild ran on, and its completion
+    hipEvent_t shadow8_ready = nullptr;
+    int64_t stat_shadow8_builds = 0, stat_shadow8_passes = 0;
+
     // IVF (optional): rows regrouped by coarse list, original slots, list offsets, the coarse index
     codd_knn_index* coarse = nullptr;  // nlist centroids, f32
     void* rows_ivf = nullptr;
@@ -553,6 +696,16 @@ thread_local char g_err[512] = "";
 int fail(int code, const char* fmt, const char* detail = "") {
     snprintf(g_err, sizeof(g_err), fmt, detail);
     return code;
+}
+
+// every row write: bumps the epoch (IVF / int8 shadow staleness) and widens the dirty row range
+void rows_written(codd_knn_index* ix, int64_t lo, int64_t hi) {
+    ix->epoch++;
+    if (ix->dirty_hi <= ix->dirty_lo) { ix->dirty_lo = lo; ix->dirty_hi = hi; }
+    else {
+        if (lo < ix->dirty_lo) ix->dirty_lo = lo;
+        if (hi > ix->dirty_hi) ix->dirty_hi = hi;
+    }
 }
 
 #define HIP_TRY(expr)                                                                        \
@@ -847,24 +1000,24 @@ float filter_eps(const codd_knn_index* ix) {
 
 template <int DT, int NITER>
 void launch_finalize_slots(int slots, int B, hipStream_t st, const codd_knn_index* ix, const float* qn, int k, float two_eps,
-                           uint32_t row_base, u64* out_keys) {
+                           uint32_t row_base, u64* out_keys, const float* two_eps_q, int nparts, u64* part_keys) {
     FilterCtl* c = ix->ctl;
     if (slots == 1)
-        hipLaunchKernelGGL((finalize_kernel<DT, NITER, 1>), dim3(B), dim3(256), 0, st, ix->rows, ix->dpad, qn, ix->hits, c->hit_cnt,
-                           ix->hit_cap_q, c->flags, k, two_eps, row_base, out_keys, &c->fb_count, c->fb_list, ix->dstats);
+        hipLaunchKernelGGL((finalize_kernel<DT, NITER, 1>), dim3(B, nparts), dim3(256), 0, st, ix->rows, ix->dpad, qn, ix->hits, c->hit_cnt,
+                           ix->hit_cap_q, c->flags, k, two_eps, row_base, out_keys, &c->fb_count, c->fb_list, ix->dstats, two_eps_q, part_keys);
     else
-        hipLaunchKernelGGL((finalize_kernel<DT, NITER, 2>), dim3(B), dim3(256), 0, st, ix->rows, ix->dpad, qn, ix->hits, c->hit_cnt,
-                           ix->hit_cap_q, c->flags, k, two_eps, row_base, out_keys, &c->fb_count, c->fb_list, ix->dstats);
+        hipLaunchKernelGGL((finalize_kernel<DT, NITER, 2>), dim3(B, nparts), dim3(256), 0, st, ix->rows, ix->dpad, qn, ix->hits, c->hit_cnt,
+                           ix->hit_cap_q, c->flags, k, two_eps, row_base, out_keys, &c->fb_count, c->fb_list, ix->dstats, two_eps_q, part_keys);
 }
 
 template <int DT>
 int launch_finalize(int niter, int slots, int B, hipStream_t st, const codd_knn_index* ix, const float* qn, int k, float two_eps,
-                    uint32_t row_base, u64* out_keys) {
+                    uint32_t row_base, u64* out_keys, const float* two_eps_q = nullptr, int nparts = 1, u64* part_keys = nullptr) {
     switch (niter) {
-        case 1: launch_finalize_slots<DT, 1>(slots, B, st, ix, qn, k, two_eps, row_base, out_keys); break;
-        case 2: launch_finalize_slots<DT, 2>(slots, B, st, ix, qn, k, two_eps, row_base, out_keys); break;
-        case 3: launch_finalize_slots<DT, 3>(slots, B, st, ix, qn, k, two_eps, row_base, out_keys); break;
-        case 4: launch_finalize_slots<DT, 4>(slots, B, st, ix, qn, k, two_eps, row_base, out_keys); break;
+        case 1: launch_finalize_slots<DT, 1>(slots, B, st, ix, qn, k, two_eps, row_base, out_keys, two_eps_q, nparts, part_keys); break;
+        case 2: launch_finalize_slots<DT, 2>(slots, B, st, ix, qn, k, two_eps, row_base, out_keys, two_eps_q, nparts, part_keys); break;
+        case 3: launch_finalize_slots<DT, 3>(slots, B, st, ix, qn, k, two_eps, row_base, out_keys, two_eps_q, nparts, part_keys); break;
+        case 4: launch_finalize_slots<DT, 4>(slots, B, st, ix, qn, k, two_eps, row_base, out_keys, two_eps_q, nparts, part_keys); break;
         default: return fail(CODD_KNN_ENOTSUP, "row too wide for the finalize kernel%s");
     }
     HIP_TRY(hipGetLastError());
@@ -904,8 +1057,8 @@ int ensure_filter_workspace(codd_knn_index* ix) {
 // how many evenly spaced tiles set the thresholds: ~ntiles/sample_div (so the sample costs a fixed
 // fraction of the main pass at every shard size and the hit volume per query stays ~k*sample_div),
 // at least max(64, 4k) where the corpus has that many tiles, at most sample_tiles
-int64_t sample_tile_count(const codd_knn_index* ix, int64_t ntiles, int k) {
-    int64_t ts = ntiles / ix->sample_div;
+int64_t sample_tile_count(const codd_knn_index* ix, int64_t ntiles, int k, bool use8 = false) {
+    int64_t ts = ntiles / (use8 ? ix->sample_div8 : ix->sample_div);
     const int64_t lo = 4 * (int64_t)k > 64 ? 4 * (int64_t)k : 64;
     if (ts < lo) ts = lo;
     // a sample of fewer tiles than there are CUs takes as long as one full round of workgroups (one tile each), and a
@@ -916,11 +1069,68 @@ int64_t sample_tile_count(const codd_knn_index* ix, int64_t ntiles, int k) {
     return ts < 1 ? 1 : ts;
 }
 
+int dpad8_of(const codd_knn_index* ix) { return (ix->dpad + 127) / 128 * 128; }
+
+// The int8 shadow is derived data: (re)built from the stored rows on the searching stream whenever rows have been
+// written since the last build.  Other streams that search before the build has finished wait for it on the device.
+int ensure_shadow8(codd_knn_index* ix, hipStream_t st) {
+    const int64_t n = ix->count;
+    const int dpad8 = dpad8_of(ix);
+    if (ix->shadow8_epoch == ix->epoch && ix->shadow8) {
+        if (st != ix->shadow8_stream && ix->shadow8_ready) HIP_TRY(hipStreamWaitEvent(st, ix->shadow8_ready, 0));
+        return CODD_KNN_OK;
+    }
+    const int64_t need = (n + kTileRows - 1) / kTileRows * kTileRows;
+    int64_t first = ix->dirty_lo, m = ix->dirty_hi - ix->dirty_lo;  // rows to (re)quantise
+    if (!ix->eps_r_bits) {
+        HIP_TRY(hipMalloc((void**)&ix->eps_r_bits, sizeof(unsigned)));
+        HIP_TRY(hipMemsetAsync(ix->eps_r_bits, 0, sizeof(unsigned), st));
+    }
+    if (need > ix->shadow8_rows) {
+        // (every stream that may still read the old allocation has to be done with it)
+        HIP_TRY(hipDeviceSynchronize());
+        if (ix->shadow8) (void)hipFree(ix->shadow8);
+        if (ix->rscale) (void)hipFree(ix->rscale);
+        ix->shadow8 = nullptr; ix->rscale = nullptr; ix->shadow8_rows = 0;
+        const int64_t rows = need + need / 8;  // head room: appends do not reallocate every time
+        const int64_t rows_al = (rows + kTileRows - 1) / kTileRows * kTileRows;
+        HIP_TRY(hipMalloc((void**)&ix->shadow8, (size_t)rows_al * dpad8));
+        HIP_TRY(hipMalloc((void**)&ix->rscale, (size_t)rows_al * sizeof(float)));
+        ix->shadow8_rows = rows_al;
+        // rows beyond the count are masked (row < n), their bytes only have to be defined
+        HIP_TRY(hipMemsetAsync(ix->shadow8, 0, (size_t)rows_al * dpad8, st));
+        HIP_TRY(hipMemsetAsync(ix->eps_r_bits, 0, sizeof(unsigned), st));
+        first = 0; m = n;  // a fresh allocation holds nothing yet
+    }
+    if (!ix->shadow8_ready) HIP_TRY(hipEventCreateWithFlags(&ix->shadow8_ready, hipEventDisableTiming));
+    if (m > 0) {
+        // an update only ever raises *eps_r (the bound stays valid for rows that have been overwritten since)
+        const dim3 grid((unsigned)((m + 3) / 4)), block(256);
+        uint32_t* s8 = reinterpret_cast<uint32_t*>(ix->shadow8);
+        switch (ix->dtype) {
+            case DT_F32: hipLaunchKernelGGL(shadow8_from_rows_kernel<DT_F32>, grid, block, 0, st, ix->rows, first, m, ix->dpad, dpad8, s8, ix->rscale, ix->eps_r_bits); break;
+            case DT_BF16: hipLaunchKernelGGL(shadow8_from_rows_kernel<DT_BF16>, grid, block, 0, st, ix->rows, first, m, ix->dpad, dpad8, s8, ix->rscale, ix->eps_r_bits); break;
+            default: hipLaunchKernelGGL(shadow8_from_rows_kernel<DT_F16>, grid, block, 0, st, ix->rows, first, m, ix->dpad, dpad8, s8, ix->rscale, ix->eps_r_bits); break;
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(ix->shadow8_ready, st));
+    ix->shadow8_stream = st;
+    ix->shadow8_epoch = ix->epoch;
+    ix->dirty_lo = ix->dirty_hi = 0;
+    ix->stat_shadow8_builds++;
+    return CODD_KNN_OK;
+}
+
 // one pass of <= 256 queries through sample -> threshold -> filter -> finalize (+ exact fallback)
 int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row_base, u64* keys_out, hipStream_t st,
-                bool prepared = false) {
+                bool prepared = false, bool use8 = false) {
     const int64_t n = ix->count;
-    const int nsteps = ix->dpad / 64;
+    const int nsteps = use8 ? dpad8_of(ix) / 128 : ix->dpad / 64;
+    const uint4* shadow = use8 ? ix->shadow8 : ix->shadow;
+    const uint4* qfrag = use8 ? ix->qfrag8 : ix->qfrag;
+    const float* slack_q = use8 ? ix->qmeta + 256 : nullptr;  // int8: 2*eps per query, written by prep_queries8_kernel
+    if (use8) ix->stat_shadow8_passes++;
     const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
     const int slots = k <= 64 ? 1 : 2;
     const float eps = filter_eps(ix);
@@ -934,7 +1144,7 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     }
 
     // sample: every `stride`-th tile
-    const int64_t ts = sample_tile_count(ix, ntiles, k);
+    const int64_t ts = sample_tile_count(ix, ntiles, k, use8);
     const int64_t stride = ntiles / ts;
     const int nbq = nq <= 32 ? 1 : (nq <= 64 ? 2 : (nq <= 128 ? 4 : 8));  // 32-query blocks the GEMM multiplies
     {
@@ -942,8 +1152,14 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
         const dim3 g((unsigned)(ts < ix->num_cus ? ts : ix->num_cus)), b(kFilterThreads);
         const size_t lds = filter_lds_bytes(MODE_SAMPLE);
 #define CODD_LAUNCH_SAMPLE(NBQ)                                                                                              \
-    hipLaunchKernelGGL((gemm_filter_kernel<MODE_SAMPLE, NBQ>), g, b, lds, st, ix->shadow, ix->qfrag, n, nsteps, ts, stride, \
+    hipLaunchKernelGGL((gemm_filter_kernel<MODE_SAMPLE, NBQ>), g, b, lds, st, shadow, qfrag, n, nsteps, ts, stride, \
                        nullptr, ix->bucket_max, nullptr, nullptr, 0, nullptr, nullptr)
+#define CODD_LAUNCH_SAMPLE8(NBQ)                                                                                             \
+    hipLaunchKernelGGL((gemm_filter_kernel<MODE_SAMPLE, NBQ, 1>), g, b, lds, st, shadow, qfrag, n, nsteps, ts, stride, \
+                       nullptr, ix->bucket_max, nullptr, nullptr, 0, nullptr, nullptr, ix->rscale, ix->qmeta)
+        if (use8) {
+            if (nbq == 1) CODD_LAUNCH_SAMPLE8(1); else CODD_LAUNCH_SAMPLE8(2);
+        } else
         switch (nbq) {
             case 1: CODD_LAUNCH_SAMPLE(1); break;
             case 2: CODD_LAUNCH_SAMPLE(2); break;
@@ -951,20 +1167,27 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
             default: CODD_LAUNCH_SAMPLE(8); break;
         }
 #undef CODD_LAUNCH_SAMPLE
+#undef CODD_LAUNCH_SAMPLE8
     }
     HIP_TRY(hipGetLastError());
     if (slots == 1)
-        hipLaunchKernelGGL(select_thr_kernel<1>, dim3(kTileQ), dim3(64), 0, st, ix->bucket_max, ts, nq, k, 2.0f * eps, ix->thr);
+        hipLaunchKernelGGL(select_thr_kernel<1>, dim3(kTileQ), dim3(64), 0, st, ix->bucket_max, ts, nq, k, 2.0f * eps, ix->thr, slack_q);
     else
-        hipLaunchKernelGGL(select_thr_kernel<2>, dim3(kTileQ), dim3(64), 0, st, ix->bucket_max, ts, nq, k, 2.0f * eps, ix->thr);
+        hipLaunchKernelGGL(select_thr_kernel<2>, dim3(kTileQ), dim3(64), 0, st, ix->bucket_max, ts, nq, k, 2.0f * eps, ix->thr, slack_q);
     HIP_TRY(hipGetLastError());
     {
         EvScope ev(ix, EV_FILTER, st);
         const dim3 g((unsigned)(ntiles < ix->num_cus ? ntiles : ix->num_cus)), b(kFilterThreads);
         const size_t lds = filter_lds_bytes(MODE_FILTER);
 #define CODD_LAUNCH_FILTER(NBQ)                                                                                             \
-    hipLaunchKernelGGL((gemm_filter_kernel<MODE_FILTER, NBQ>), g, b, lds, st, ix->shadow, ix->qfrag, n, nsteps, ntiles,     \
+    hipLaunchKernelGGL((gemm_filter_kernel<MODE_FILTER, NBQ>), g, b, lds, st, shadow, qfrag, n, nsteps, ntiles,     \
                        (int64_t)1, ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, nullptr)
+#define CODD_LAUNCH_FILTER8(NBQ)                                                                                            \
+    hipLaunchKernelGGL((gemm_filter_kernel<MODE_FILTER, NBQ, 1>), g, b, lds, st, shadow, qfrag, n, nsteps, ntiles,  \
+                       (int64_t)1, ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, nullptr, ix->rscale, ix->qmeta)
+        if (use8) {
+            if (nbq == 1) CODD_LAUNCH_FILTER8(1); else CODD_LAUNCH_FILTER8(2);
+        } else
         switch (nbq) {
             case 1: CODD_LAUNCH_FILTER(1); break;
             case 2: CODD_LAUNCH_FILTER(2); break;
@@ -972,19 +1195,25 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
             default: CODD_LAUNCH_FILTER(8); break;
         }
 #undef CODD_LAUNCH_FILTER
+#undef CODD_LAUNCH_FILTER8
     }
     HIP_TRY(hipGetLastError());
     const int nchunks = ix->dpad / elems_per_chunk(ix->dtype);
     const int niter = (nchunks + kWave - 1) / kWave;
+    // the int8 filter leaves thousands of survivors per query and is only used for a handful of queries: share each
+    // query's re-scoring out between several workgroups, then merge their lists
+    const int nparts = use8 ? (nq <= 8 ? 16 : 8) : 1;
+    if (nparts > 1 && (rc = ensure_buf(&ix->partial, &ix->partial_cap, (int64_t)nq * nparts * k)) != 0) return rc;
     {
         EvScope ev(ix, EV_FINALIZE, st);
         switch (ix->dtype) {
-            case DT_F32: rc = launch_finalize<DT_F32>(niter, slots, nq, st, ix, qn, k, 2.0f * eps, row_base, keys_out); break;
-            case DT_BF16: rc = launch_finalize<DT_BF16>(niter, slots, nq, st, ix, qn, k, 2.0f * eps, row_base, keys_out); break;
-            default: rc = launch_finalize<DT_F16>(niter, slots, nq, st, ix, qn, k, 2.0f * eps, row_base, keys_out); break;
+            case DT_F32: rc = launch_finalize<DT_F32>(niter, slots, nq, st, ix, qn, k, 2.0f * eps, row_base, keys_out, slack_q, nparts, ix->partial); break;
+            case DT_BF16: rc = launch_finalize<DT_BF16>(niter, slots, nq, st, ix, qn, k, 2.0f * eps, row_base, keys_out, slack_q, nparts, ix->partial); break;
+            default: rc = launch_finalize<DT_F16>(niter, slots, nq, st, ix, qn, k, 2.0f * eps, row_base, keys_out, slack_q, nparts, ix->partial); break;
         }
     }
     if (rc != 0) return rc;
+    if (nparts > 1 && (rc = launch_merge(ix->partial, nq, (int64_t)nparts * k, (int64_t)nparts * k, k, keys_out, nullptr, nullptr, st)) != 0) return rc;
 
     // exact-scan fallback for the queries finalize queued (normally none), entirely on the device: the
     // scan walks the queue (an empty queue costs two empty launches), the merge writes each answer into
@@ -1040,7 +1269,18 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
     if ((rc = ensure_buf(&ix->keys_tmp, &ix->keys_tmp_cap, (int64_t)B * k)) != 0) return rc;
     const bool use_filter = n > 0 && filter_applies(ix, B, k);
     const bool fused_prep = use_filter && B <= kTileQ;
-    if (fused_prep) {
+    const bool use8 = fused_prep && ix->shadow8_enabled && B <= ix->shadow8_max_batch && B <= 64 && CODD_MFMA16;
+    if (use8) {
+        if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
+        if ((rc = ensure_shadow8(ix, st)) != 0) return rc;
+        const int dpad8 = dpad8_of(ix);
+        if ((rc = ensure_buf(&ix->qfrag8, &ix->qfrag8_cap, (int64_t)kTileQ * (dpad8 / 16))) != 0) return rc;
+        if (!ix->qmeta) HIP_TRY(hipMalloc((void**)&ix->qmeta, 512 * sizeof(float)));
+        hipLaunchKernelGGL(prep_queries8_kernel, dim3(kTileQ / 4), dim3(256), 0, st, dev_queries, B, ix->dim, ix->dpad, dpad8, ix->qn,
+                           reinterpret_cast<uint32_t*>(ix->qfrag8), ix->qmeta, ix->eps_r_bits, reinterpret_cast<unsigned*>(ix->ctl),
+                           (int)(sizeof(FilterCtl) / 4));
+        HIP_TRY(hipGetLastError());
+    } else if (fused_prep) {
         if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
         hipLaunchKernelGGL(prep_queries_kernel, dim3(kTileQ / 4), dim3(256), 0, st, dev_queries, B, ix->dim, ix->dpad, ix->qn,
                            reinterpret_cast<uint2*>(ix->qfrag), reinterpret_cast<unsigned*>(ix->ctl), (int)(sizeof(FilterCtl) / 4));
@@ -1060,7 +1300,7 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
         if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
         for (int q0 = 0; q0 < B; q0 += kTileQ) {
             const int nq = B - q0 < kTileQ ? B - q0 : kTileQ;
-            if ((rc = filter_pass(ix, ix->qn + (int64_t)q0 * ix->dpad, nq, k, row_base, keys_dst + (int64_t)q0 * k, st, fused_prep)) != 0)
+            if ((rc = filter_pass(ix, ix->qn + (int64_t)q0 * ix->dpad, nq, k, row_base, keys_dst + (int64_t)q0 * k, st, fused_prep, use8)) != 0)
                 return rc;
         }
     } else {
@@ -1120,12 +1360,13 @@ int codd_knn_destroy(codd_knn_index* ix) {
     if (!ix) return CODD_KNN_OK;
     DeviceGuard guard(ix->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = {ix->rows, ix->shadow, ix->dstats, ix->rows_ivf, ix->ivf_ids, ix->ivf_offsets};
+    void* bufs[] = {ix->rows, ix->shadow, ix->dstats, ix->rows_ivf, ix->ivf_ids, ix->ivf_offsets, ix->shadow8, ix->rscale, ix->eps_r_bits};
+    if (ix->shadow8_ready) (void)hipEventDestroy(ix->shadow8_ready);
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (WorkSlot& w : ix->slots) {
         void* wb[] = {w.bufs.qn, w.bufs.partial, w.bufs.keys_tmp, w.bufs.qfrag, w.bufs.thr, w.bufs.bucket_max, w.bufs.hits, w.bufs.ctl,
-                      w.bufs.fb_partial, w.bufs.probe_keys, w.bufs.ivf_partial};
+                      w.bufs.fb_partial, w.bufs.probe_keys, w.bufs.ivf_partial, w.bufs.qfrag8, w.bufs.qmeta};
         for (void* b : wb)
             if (b) (void)hipFree(b);
         if (w.handover) (void)hipEventDestroy(w.handover);
@@ -1148,10 +1389,11 @@ int codd_knn_reserve(codd_knn_index* ix, int64_t rows) {
 int codd_knn_upsert_host(codd_knn_index* ix, const int64_t* host_slots, const float* host_vecs, int64_t n, int normalize) {
     if (!ix || (n > 0 && (!host_slots || !host_vecs)) || n < 0) return fail(CODD_KNN_EINVAL, "bad upsert arguments%s");
     if (n == 0) return CODD_KNN_OK;
-    int64_t max_slot = -1;
+    int64_t max_slot = -1, min_slot = INT64_MAX;
     for (int64_t i = 0; i < n; ++i) {
         if (host_slots[i] < 0 || host_slots[i] >= 0xfffffffell) return fail(CODD_KNN_EINVAL, "row slot out of range%s");
         if (host_slots[i] > max_slot) max_slot = host_slots[i];
+        if (host_slots[i] < min_slot) min_slot = host_slots[i];
     }
     DeviceGuard guard(ix->device);
     HIP_TRY(hipDeviceSynchronize());
@@ -1183,7 +1425,7 @@ int codd_knn_upsert_host(codd_knn_index* ix, const int64_t* host_slots, const fl
     (void)hipFree(dslot);
     if (rc == 0) {
         if (max_slot + 1 > ix->count) ix->count = max_slot + 1;
-        ix->epoch++;
+        rows_written(ix, min_slot, max_slot + 1);
         if (!normalize) ix->all_normalized = false;
     }
     return rc;
@@ -1203,7 +1445,7 @@ int codd_knn_upsert_device(codd_knn_index* ix, int64_t first_slot, const float* 
                               reinterpret_cast<uint2*>(ix->shadow), (hipStream_t)stream);
     if (rc != 0) return rc;
     if (first_slot + n > ix->count) ix->count = first_slot + n;
-    ix->epoch++;
+    rows_written(ix, first_slot, first_slot + n);
     if (!normalize) ix->all_normalized = false;
     return CODD_KNN_OK;
 }
@@ -1228,7 +1470,7 @@ int codd_knn_load_rows(codd_knn_index* ix, int64_t first_slot, const void* host_
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     if (first_slot + n > ix->count) ix->count = first_slot + n;
-    ix->epoch++;
+    rows_written(ix, first_slot, first_slot + n);
     return CODD_KNN_OK;
 }
 
@@ -1295,6 +1537,23 @@ int codd_knn_approx_scores(codd_knn_index* ix, const float* dev_queries, int B, 
     int rc;
     if ((rc = ensure_buf(&ix->qn, &ix->qn_cap, (int64_t)B * ix->dpad)) != 0) return rc;
     if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
+    if (ix->shadow8_enabled && B <= 32 && CODD_MFMA16) {
+        // the int8 filter's scores (what a batch of <= 32 queries is filtered with when "shadow8" is on)
+        if ((rc = ensure_shadow8(ix, st)) != 0) return rc;
+        const int dpad8 = dpad8_of(ix);
+        if ((rc = ensure_buf(&ix->qfrag8, &ix->qfrag8_cap, (int64_t)kTileQ * (dpad8 / 16))) != 0) return rc;
+        if (!ix->qmeta) HIP_TRY(hipMalloc((void**)&ix->qmeta, 512 * sizeof(float)));
+        hipLaunchKernelGGL(prep_queries8_kernel, dim3(kTileQ / 4), dim3(256), 0, st, dev_queries, B, ix->dim, ix->dpad, dpad8, ix->qn,
+                           reinterpret_cast<uint32_t*>(ix->qfrag8), ix->qmeta, ix->eps_r_bits, reinterpret_cast<unsigned*>(ix->ctl),
+                           (int)(sizeof(FilterCtl) / 4));
+        const int64_t ntiles8 = (ix->count + kTileRows - 1) / kTileRows;
+        const int64_t g8 = ntiles8 < ix->num_cus ? ntiles8 : ix->num_cus;
+        hipLaunchKernelGGL((gemm_filter_kernel<MODE_DUMP, 1, 1>), dim3((unsigned)g8), dim3(kFilterThreads), filter_lds_bytes(MODE_DUMP), st,
+                           ix->shadow8, ix->qfrag8, ix->count, dpad8 / 128, ntiles8, (int64_t)1, nullptr, nullptr, nullptr, nullptr, 0, nullptr,
+                           dev_scores, ix->rscale, ix->qmeta);
+        HIP_TRY(hipGetLastError());
+        return CODD_KNN_OK;
+    }
     if ((rc = launch_normalize(DT_F32, dev_queries, B, ix->dim, ix->dpad, 1, nullptr, 0, ix->qn, nullptr, st)) != 0) return rc;
     hipLaunchKernelGGL(qfrag_kernel, dim3((kTileQ * (ix->dpad / 8) + 255) / 256), dim3(256), 0, st, ix->qn, B, ix->dpad, ix->qfrag,
                        (unsigned*)nullptr, 0);
@@ -1416,6 +1675,21 @@ int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {
     if (strcmp(key, "filter_min_rows") == 0) { ix->filter_min_rows = value < 1 ? 1 : value; return CODD_KNN_OK; }
     if (strcmp(key, "filter_min_rows_small") == 0) { ix->filter_min_rows_small = value < 1 ? 1 : value; return CODD_KNN_OK; }
     if (strcmp(key, "filter_min_batch") == 0) { ix->filter_min_batch = value < 1 ? 1 : (int)value; return CODD_KNN_OK; }
+    if (strcmp(key, "shadow8") == 0) {
+        if (value != 0 && value != 1) return fail(CODD_KNN_EINVAL, "shadow8 must be 0 or 1%s");
+        ix->shadow8_enabled = (int)value;
+        return CODD_KNN_OK;
+    }
+    if (strcmp(key, "shadow8_max_batch") == 0) {
+        if (value < 1 || value > 64) return fail(CODD_KNN_EINVAL, "shadow8_max_batch must be in [1,64]%s");
+        ix->shadow8_max_batch = (int)value;
+        return CODD_KNN_OK;
+    }
+    if (strcmp(key, "sample_div8") == 0) {
+        if (value < 1 || value > 1000) return fail(CODD_KNN_EINVAL, "sample_div8 must be in [1,1000]%s");
+        ix->sample_div8 = (int)value;
+        return CODD_KNN_OK;
+    }
     if (strcmp(key, "sample_tiles") == 0) {
         if (value < 1 || value > 65536) return fail(CODD_KNN_EINVAL, "sample_tiles must be in [1,65536]%s");
         ix->sample_tiles = (int)value;
@@ -1478,6 +1752,8 @@ int codd_knn_get_stat(const codd_knn_index* ix, const char* key, int64_t* out) {
     else if (strcmp(key, "scan_launches") == 0) *out = ix->stat_scan_launches;
     else if (strcmp(key, "last_scan_blocks") == 0) *out = ix->stat_last_scan_blocks;
     else if (strcmp(key, "filter_passes") == 0) *out = ix->stat_filter_passes;
+    else if (strcmp(key, "shadow8_builds") == 0) *out = ix->stat_shadow8_builds;
+    else if (strcmp(key, "shadow8_passes") == 0) *out = ix->stat_shadow8_passes;
     else if (strcmp(key, "fallback_queries") == 0 || strcmp(key, "filter_hits") == 0 || strcmp(key, "filter_survivors") == 0) {
         // device-side counters (the search itself never reads them back): synchronises
         unsigned long long h[4] = {0, 0, 0, 0};
@@ -1491,7 +1767,8 @@ int codd_knn_get_stat(const codd_knn_index* ix, const char* key, int64_t* out) {
     else if (strcmp(key, "capacity_rows") == 0) *out = ix->capacity;
     else if (strcmp(key, "num_cus") == 0) *out = ix->num_cus;
     else if (strcmp(key, "device_bytes") == 0) {
-        int64_t b = ix->capacity * (int64_t)ix->dpad * (int64_t)elem_size(ix->dtype) + ix->shadow_rows * (int64_t)ix->dpad * 2;
+        int64_t b = ix->capacity * (int64_t)ix->dpad * (int64_t)elem_size(ix->dtype) + ix->shadow_rows * (int64_t)ix->dpad * 2 +
+                    ix->shadow8_rows * ((int64_t)dpad8_of(ix) + 4);
         for (const WorkSlot& w : ix->slots)
             b += w.bufs.qn_cap * 4 + w.bufs.partial_cap * 8 + w.bufs.keys_tmp_cap * 8 + w.bufs.hits_cap * 8 + w.bufs.bucket_cap * 4 +
                  w.bufs.qfrag_cap * 16 + w.bufs.fb_partial_cap * 8 + w.bufs.probe_cap * 8 + w.bufs.ivf_partial_cap * 8;

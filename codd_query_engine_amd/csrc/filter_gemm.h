@@ -280,11 +280,18 @@ __device__ __forceinline__ void flush_hits_binned(const unsigned* lds_hits, unsi
 //   MODE_DUMP  : all scores to dump[query][row] (diagnostics / layout tests, small n only)
 // Run-tile u (0 <= u < ntiles_run) is corpus tile u*tile_stride; workgroup b takes u = b, b+G, ...
 // ---------------------------------------------------------------------------------------------
-template <int MODE, int NBQ>
+// EL = 1: the operands are int8 with one fp32 scale per corpus row (rscale) and per query (qscale): 128 elements per
+// K-step instead of 64, v_mfma_i32_16x16x64_i8 (twice the bf16 rate, half the bytes), exact integer accumulation; a
+// score is acc * rscale[row] * qscale[query].  The piece / ring / LDS geometry is byte-identical to the bf16 mode.
+template <int MODE, int NBQ, int EL = 0>
 __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gemm_filter_kernel(
     const uint4* __restrict__ shadow, const uint4* __restrict__ qfrag, int64_t n, int nsteps, int64_t ntiles_run,
     int64_t tile_stride, const float* __restrict__ thr, float* __restrict__ bucket_max, u64* __restrict__ hits,
-    unsigned* __restrict__ hit_cnt, int cap_q, unsigned* __restrict__ flags, float* __restrict__ dump) {
+    unsigned* __restrict__ hit_cnt, int cap_q, unsigned* __restrict__ flags, float* __restrict__ dump,
+    const float* __restrict__ rscale = nullptr, const float* __restrict__ qscale = nullptr) {
+    static_assert(EL == 0 || (CODD_MFMA16 && kKS == 2), "the int8 mode is written for the 16x16 MFMA geometry");
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    typedef typename std::conditional<EL == 1, i32x4, acc_t>::type accv_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* ldsQ = reinterpret_cast<uint4*>(smem);                        // 2 stages x kQS slices x 32 KiB
     unsigned* lds_w = reinterpret_cast<unsigned*>(smem + kLdsQBytes);    // [0..255] thr / bucket max, [256] hit count
@@ -310,7 +317,9 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
     if (T == 0) return;
 
     if (MODE == MODE_FILTER) {
-        if (tid < 256) lds_w[tid] = __float_as_uint(thr[tid]);
+        // int8: the test runs on acc * rscale[row], so the threshold carries the query's scale (a zero query has
+        // scale 0: every score is 0 and its threshold becomes -inf or +inf by sign)
+        if (tid < 256) lds_w[tid] = __float_as_uint(EL ? thr[tid] / qscale[tid] : thr[tid]);
         if (tid == 0) lds_w[256] = 0u;
     } else if (MODE == MODE_SAMPLE) {
         if (tid < 256) lds_w[tid] = 0u;
@@ -321,13 +330,13 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
     constexpr int NQBall = NBQ * kQBper32;       // MFMA query blocks of the pass
     constexpr int NQB = NQBall / kQSplit;        // ... of this wave
     static_assert(NQBall % kQSplit == 0, "query blocks must split evenly");
-    acc_t acc[kRS][NQB];
+    accv_t acc[kRS][NQB];
 #pragma unroll
     for (int rs = 0; rs < kRS; ++rs)
 #pragma unroll
         for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
-            for (int i = 0; i < kAccRegs; ++i) acc[rs][qb][i] = 0.0f;
+            for (int i = 0; i < kAccRegs; ++i) acc[rs][qb][i] = 0;
 
     // load cursor (runs kPrefetch steps ahead of the compute cursor)
     int64_t l_u = first_u;  // run-tile ordinal
@@ -422,6 +431,11 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                 for (int rs = 0; rs < kRS; ++rs) {
                     // row block rs lives in 32-row block rs / (32/kMB), sub-block rs % (32/kMB)
                     const bf16x8 a = __builtin_bit_cast(bf16x8, ring[slot][rs / kQBper32][a_piece(rs % kQBper32, ks)]);
+                    if constexpr (EL == 1) {
+#if CODD_MFMA16
+                        acc[rs][qb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a), __builtin_bit_cast(i32x4, b), acc[rs][qb], 0, 0, 0);
+#endif
+                    } else {
 #if CODD_MFMA16 && CODD_SHADOW_F16
                     acc[rs][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[rs][qb], 0, 0, 0);
 #elif CODD_MFMA16
@@ -431,6 +445,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
 #else
                     acc[rs][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[rs][qb], 0, 0, 0);
 #endif
+                    }
                 }
             }
         }
@@ -443,13 +458,19 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
 #pragma unroll
             for (int rs = 0; rs < kRS; ++rs) {
                 const int64_t row0 = tile * kTileRows + wr * (32 * kRB) + rs * kMB;  // + acc_row(r, lane)
+                float rsc[kAccRegs];  // int8: this lane's row scales
+#pragma unroll
+                for (int r = 0; r < kAccRegs; ++r) rsc[r] = (EL && row0 + acc_row(r, lane) < n) ? rscale[row0 + acc_row(r, lane)] : 0.0f;
                 if (MODE == MODE_FILTER) {
 #pragma unroll
                     for (int qb = 0; qb < NQB; ++qb) {
                         const float th = CODD_EXP_NO_HITS ? INFINITY : __uint_as_float(lds_w[qbase + qb * kMB]);
-                        float m = acc[rs][qb][0];
+                        float v4[kAccRegs];
 #pragma unroll
-                        for (int r = 1; r < kAccRegs; ++r) m = fmaxf(m, acc[rs][qb][r]);
+                        for (int r = 0; r < kAccRegs; ++r) v4[r] = EL ? (float)acc[rs][qb][r] * rsc[r] : (float)acc[rs][qb][r];
+                        float m = v4[0];
+#pragma unroll
+                        for (int r = 1; r < kAccRegs; ++r) m = fmaxf(m, v4[r]);
                         if (__any(m >= th)) {
 #if CODD_BALLOT_HITS
                             // one LDS atomic per block that has hits (lane 0 reserves the block's slots, every
@@ -457,18 +478,18 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                             unsigned tot = 0;
 #pragma unroll
                             for (int r = 0; r < kAccRegs; ++r)
-                                tot += (unsigned)__popcll(__ballot(acc[rs][qb][r] >= th && row0 + acc_row(r, lane) < n));
+                                tot += (unsigned)__popcll(__ballot(v4[r] >= th && row0 + acc_row(r, lane) < n));
                             unsigned base = 0;
                             if (lane == 0) base = atomicAdd(&lds_w[256], tot);
                             base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
 #pragma unroll
                             for (int r = 0; r < kAccRegs; ++r) {
-                                const bool hit = acc[rs][qb][r] >= th && row0 + acc_row(r, lane) < n;
+                                const bool hit = v4[r] >= th && row0 + acc_row(r, lane) < n;
                                 const unsigned long long mk = __ballot(hit);
                                 if (hit) {
                                     const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
                                     if (slot < (unsigned)kHitCap) {
-                                        lds_hits[slot * 3 + 0] = __float_as_uint(acc[rs][qb][r]);
+                                        lds_hits[slot * 3 + 0] = __float_as_uint(EL ? v4[r] * qscale[qbase + qb * kMB] : v4[r]);
                                         lds_hits[slot * 3 + 1] = (unsigned)(row0 + acc_row(r, lane));
                                         lds_hits[slot * 3 + 2] = (unsigned)(qbase + qb * kMB);
                                     } else {
@@ -480,12 +501,12 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
 #else
 #pragma unroll
                             for (int r = 0; r < kAccRegs; ++r) {
-                                const float v = acc[rs][qb][r];
+                                const float v = v4[r];
                                 const int64_t row = row0 + acc_row(r, lane);
                                 if (v >= th && row < n) {
                                     const unsigned slot = atomicAdd(&lds_w[256], 1u);
                                     if (slot < (unsigned)kHitCap) {
-                                        lds_hits[slot * 3 + 0] = __float_as_uint(v);
+                                        lds_hits[slot * 3 + 0] = __float_as_uint(EL ? v * qscale[qbase + qb * kMB] : v);
                                         lds_hits[slot * 3 + 1] = (unsigned)row;
                                         lds_hits[slot * 3 + 2] = (unsigned)(qbase + qb * kMB);
                                     } else {
@@ -510,7 +531,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
 #pragma unroll
                         for (int r = 0; r < kAccRegs; ++r) {
                             const int64_t row = row0 + acc_row(r, lane);
-                            const float v = (!ragged || row < n) ? acc[rs][qb][r] : -INFINITY;
+                            const float v = (!ragged || row < n) ? (EL ? (float)acc[rs][qb][r] * rsc[r] : (float)acc[rs][qb][r]) : -INFINITY;
                             m = fmaxf(m, v);
                         }
                         atomicMax(&lds_w[qbase + qb * kMB], ord_f32(m));
@@ -521,7 +542,9 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
 #pragma unroll
                         for (int r = 0; r < kAccRegs; ++r) {
                             const int64_t row = row0 + acc_row(r, lane);
-                            if (row < n) dump[(int64_t)(qbase + qb * kMB) * n + row] = acc[rs][qb][r];
+                            if (row < n)
+                                dump[(int64_t)(qbase + qb * kMB) * n + row] =
+                                    EL ? (float)acc[rs][qb][r] * rsc[r] * qscale[qbase + qb * kMB] : (float)acc[rs][qb][r];
                         }
                 }
             }  // rs
@@ -531,7 +554,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
 #pragma unroll
             for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
-                for (int r = 0; r < kAccRegs; ++r) acc[rs][qb][r] = 0.0f;
+                for (int r = 0; r < kAccRegs; ++r) acc[rs][qb][r] = 0;
     };
     auto slice_ptr = [&](int step) -> const uint4* {  // LDS address of the query slice of a step (4 slices, cyclic)
         return ldsQ + ((step + 4) & (2 * kQS - 1)) * kStagePieces + lane + qoff;
@@ -625,7 +648,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
 #pragma unroll
                             for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
-                                for (int r = 0; r < kAccRegs; ++r) acc[rs][qb][r] = 0.0f;
+                                for (int r = 0; r < kAccRegs; ++r) acc[rs][qb][r] = 0;
                     }
                     load_a(ring[(i + kPrefetch) % kRing]);  // the slot the second half of step t-1 has just released
                     mfma_part(std::integral_constant<int, i>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, slice_ptr(t));
@@ -671,7 +694,8 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                     // all 8 waves have folded this tile into lds_w: publish, reset, and fence the reset
                     // against the next tile's fold
                     if (tid < 256) {
-                        bucket_max[(int64_t)tid * ntiles_run + w_u] = unord_f32(lds_w[tid]);  // [query][bucket]: select_thr reads rows
+                        // [query][bucket]: select_thr reads rows.  (int8: the fold ran on acc * rscale; scale >= 0 keeps the order)
+                        bucket_max[(int64_t)tid * ntiles_run + w_u] = EL ? unord_f32(lds_w[tid]) * qscale[tid] : unord_f32(lds_w[tid]);
                         lds_w[tid] = 0u;
                     }
                     __syncthreads();
@@ -702,7 +726,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
 // ---------------------------------------------------------------------------------------------
 template <int SLOTS>
 __global__ __launch_bounds__(64) void select_thr_kernel(const float* __restrict__ bucket_max, int64_t nbuckets, int B, int k,
-                                                        float slack, float* __restrict__ thr) {
+                                                        float slack, float* __restrict__ thr, const float* __restrict__ slack_q = nullptr) {
     const int q = blockIdx.x, lane = lane_id();
     if (q >= B) {
         if (lane == 0) thr[q] = INFINITY;
@@ -715,7 +739,7 @@ __global__ __launch_bounds__(64) void select_thr_kernel(const float* __restrict_
         const u64 cand = i < nbuckets ? make_key(bucket_max[(int64_t)q * nbuckets + i], (uint32_t)i) : 0ull;
         L.offer_lanes(cand, k, lane);
     }
-    if (lane == 0) thr[q] = L.thr ? key_score(L.thr) - slack : -INFINITY;
+    if (lane == 0) thr[q] = L.thr ? key_score(L.thr) - (slack_q ? slack_q[q] : slack) : -INFINITY;  // (int8: the slack is per query)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -735,7 +759,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
                                                        int cap_q, unsigned* __restrict__ flags, int k, float two_eps,
                                                        uint32_t row_base, u64* __restrict__ out_keys,
                                                        unsigned* __restrict__ fb_count, unsigned* __restrict__ fb_list,
-                                                       unsigned long long* __restrict__ stats) {
+                                                       unsigned long long* __restrict__ stats, const float* __restrict__ two_eps_q = nullptr,
+                                                       u64* __restrict__ part_keys = nullptr) {
+    // gridDim.y > 1: the query's hit list is shared out between gridDim.y workgroups (contiguous shares), each
+    // writes its own top-k to part_keys[(q * P + p) * k ..] and a merge launch follows.  With one or a few queries
+    // and thousands of survivors (the int8 filter) one workgroup per query would do all the re-scoring on one CU.
     typedef RowTraits<DT> RT;
     constexpr int E = RT::E;
     __shared__ u64 lds_list[4 * SLOTS * kWave];
@@ -745,8 +773,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
 
     const int q = blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned total = hit_cnt[q * kHitCntStride];
+    const unsigned part = blockIdx.y, nparts = gridDim.y;
     if (total > (unsigned)cap_q) {  // the candidate list was truncated: only the exact scan can answer this query
-        if (tid == 0) {
+        if (tid == 0 && part == 0) {
             fb_list[atomicAdd(fb_count, 1u)] = (unsigned)q;
             atomicOr(&flags[FLAG_NEED_FALLBACK], 1u);
         }
@@ -782,7 +811,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
                 if (s * kWave + lane >= k) cand = 0ull;
                 L.offer_lanes(cand, k, lane);
             }
-        if (lane == 0) lds_lo = L.thr ? key_score(L.thr) - two_eps : -INFINITY;
+        if (lane == 0) lds_lo = L.thr ? key_score(L.thr) - (two_eps_q ? two_eps_q[blockIdx.x] : two_eps) : -INFINITY;
     }
     __syncthreads();
     const float lo = lds_lo;
@@ -795,10 +824,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
     // 2 + 3. round by round: survivors of the next kSurvChunk hits (approx >= a_k - 2 eps: no other row can reach
     // the exact top-k) are compacted into LDS and re-scored exactly, four rows per wave step, with the same
     // canonical expression as the scan.  No cap on the number of survivors: a dense cluster costs time, not exactness.
-    for (unsigned b0 = 0; b0 < total; b0 += kSurvChunk) {
+    const unsigned my_lo = (unsigned)((u64)total * part / nparts), my_hi = (unsigned)((u64)total * (part + 1) / nparts);  // this workgroup's share
+    for (unsigned b0 = my_lo; b0 < my_hi; b0 += kSurvChunk) {
         if (tid == 0) lds_n = 0u;
         __syncthreads();
-        const unsigned b1 = b0 + kSurvChunk < total ? b0 + kSurvChunk : total;
+        const unsigned b1 = b0 + kSurvChunk < my_hi ? b0 + kSurvChunk : my_hi;
         for (unsigned i = b0 + tid; i < b1; i += 256) {
             const u64 key = my[i];
             if (key_score(key) >= lo) lds_surv[atomicAdd(&lds_n, 1u)] = key_row(key);
@@ -840,7 +870,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
         __syncthreads();  // lds_surv is refilled by the next round
     }
     if (tid == 0 && stats) {
-        atomicAdd(&stats[0], (unsigned long long)total);
+        if (part == 0) atomicAdd(&stats[0], (unsigned long long)total);
         atomicAdd(&stats[1], (unsigned long long)survivors);
     }
 
@@ -859,7 +889,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int rank = s * kWave + lane;
-        if (rank < k) out_keys[(int64_t)q * k + rank] = X.v[s];
+        if (rank < k) (nparts > 1 ? part_keys + ((int64_t)q * nparts + part) * k : out_keys + (int64_t)q * k)[rank] = X.v[s];
     }
 }
 

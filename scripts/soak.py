@@ -9,7 +9,7 @@ from codd_query_engine_amd.knn_index import DeviceKnnIndex
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-t_end, cases, fails, fallbacks = time.time() + budget, 0, 0, 0
+t_end, cases, fails, fallbacks, passes8 = time.time() + budget, 0, 0, 0, 0
 while time.time() < t_end:
     d = int(rng.choice([64, 128, 192, 256, 320, 384, 512, 768, 1024]))
     dtype = str(rng.choice(["f32", "bf16", "f16"]))
@@ -31,9 +31,16 @@ while time.time() < t_end:
     ix.upsert_device(0, x.contiguous())
     for key in ("filter_min_rows", "filter_min_rows_small", "filter_min_batch"):
         ix.set_option(key, 1)
+    ix.set_option("shadow8_max_batch", int(rng.choice([8, 8, 64])))  # the int8 filter for small batches (sometimes up to 64)
+    if rng.random() < 0.3:  # an overwrite and an append after a first search: the int8 shadow must follow
+        ix.search_tensors(q[:1], 1)
+        x2 = torch.randn((int(rng.integers(1, 3000)), d), generator=g, device="cuda")
+        ix.upsert_device(int(rng.integers(0, n)), q[:1].contiguous())
+        ix.upsert_device(n, x2)
     df, rf = ix.search_tensors(q, k)
     used_filter = ix.stat("filter_passes") > 0
     fallbacks += ix.stat("fallback_queries")
+    passes8 += ix.stat("shadow8_passes")
     ix.set_option("filter", 0)
     de, re_ = ix.search_tensors(q, k)
     ok = bool(torch.equal(rf, re_) and torch.equal(df, de))
@@ -43,5 +50,5 @@ while time.time() < t_end:
         bad = (rf != re_).any(dim=1).nonzero().flatten().tolist()[:5]
         print(f"MISMATCH n={n} d={d} dtype={dtype} B={B} k={k} kind={kind} filter={used_filter} queries={bad}", flush=True)
     ix.close()
-print(f"soak: {cases} cases, {fails} mismatches, {fallbacks} fallback queries in {budget:.0f} s")
+print(f"soak: {cases} cases, {fails} mismatches, {fallbacks} fallback queries, {passes8} int8 passes in {budget:.0f} s")
 sys.exit(1 if fails else 0)

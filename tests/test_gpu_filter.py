@@ -32,6 +32,7 @@ def torch():
 def build(Index, raw, dtype="f32", force_filter=True):
     ix = Index(raw.shape[1], dtype=dtype)
     ix.upsert(np.arange(raw.shape[0], dtype=np.int64), raw)
+    ix.set_option("shadow8", 0)  # this file is about the bf16 filter; the int8 one (batches <= 8) has tests/test_gpu_shadow8.py
     if force_filter:
         ix.set_option("filter_min_rows", 1)
         ix.set_option("filter_min_rows_small", 1)

@@ -1,0 +1,149 @@
+"""The optional int8 shadow for small batches ("shadow8"): half the bytes of the bf16 shadow per pass.  The filter is
+still only a filter: survivors are re-scored with the canonical fp32 expression, so ids and distances must equal the
+oracle's bit for bit; what changes is the error bound (per query, from the exact quantisation error norms)."""
+
+import numpy as np
+import pytest
+
+from oracle import knn_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Index():
+    import torch
+
+    assert torch.cuda.is_available()
+    from codd_query_engine_amd.knn_index import DeviceKnnIndex
+
+    return DeviceKnnIndex
+
+
+def build8(Index, raw, dtype="f32"):
+    ix = Index(raw.shape[1], dtype=dtype)
+    ix.upsert(np.arange(raw.shape[0], dtype=np.int64), raw)
+    for key in ("filter_min_rows", "filter_min_rows_small", "filter_min_batch"):
+        ix.set_option(key, 1)
+    ix.set_option("shadow8", 1)
+    ix.set_option("shadow8_max_batch", 32)  # (default 8: beyond that the int8 filter's candidate volume outweighs the bytes it saves)
+    return ix
+
+
+def quantise_like_the_kernels(x, is_query):
+    """fp32 arithmetic of shadow8_from_rows_kernel / prep_queries8_kernel."""
+    x = x.astype(np.float32)
+    vmax = np.abs(x).max(axis=1).astype(np.float32)
+    safe = np.where(vmax > 0, vmax, np.float32(1.0)).astype(np.float32)
+    if is_query:
+        scale = np.where(vmax > 0, vmax / np.float32(127.0), np.float32(0.0)).astype(np.float32)
+        inv = np.where(vmax > 0, np.float32(127.0) / safe, np.float32(0.0)).astype(np.float32)
+    else:
+        scale = np.where(vmax > 0, vmax / np.float32(127.0), np.float32(1.0)).astype(np.float32)
+        inv = (np.float32(1.0) / scale).astype(np.float32)
+    q8 = np.clip(np.rint((x * inv[:, None]).astype(np.float32)), -127, 127).astype(np.int32)
+    return q8, scale
+
+
+@pytest.mark.parametrize("n,d,B,dtype", [(1000, 768, 20, "f32"), (300, 100, 32, "f32"), (700, 384, 7, "bf16"), (513, 1024, 1, "f16")])
+def test_int8_scores_match_integer_reference(Index, n, d, B, dtype):
+    """Operand layouts and scales: every int8 filter score equals (integer dot of the quantised operands) * row scale *
+    query scale, evaluated with the kernel's own fp32 operations — bit for bit."""
+    rng = np.random.default_rng(n + d)
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    raw[:, 0] += 3.0  # asymmetric data: a transposed or permuted operand cannot pass
+    q = rng.standard_normal((B, d)).astype(np.float32)
+    ix = build8(Index, raw, dtype)
+    got = ix.approx_scores(q).cpu().numpy()
+    assert ix.stat("shadow8_builds") == 1
+    stored = o.widen(o.to_storage(o.normalize_rows(raw), dtype), dtype)
+    c8, cs = quantise_like_the_kernels(stored, False)
+    q8, qs = quantise_like_the_kernels(o.normalize_rows(q), True)
+    acc = (q8.astype(np.int64) @ c8.astype(np.int64).T).astype(np.float32)  # |acc| < 2^24: exact in fp32
+    ref = ((acc * cs[None, :]).astype(np.float32) * qs[:, None]).astype(np.float32)
+    assert got.shape == (256, n)
+    assert np.array_equal(got[:B], ref)
+    assert not got[B:].any()
+    # and the scores are what they claim to approximate, within the bound the filter uses
+    exact = o.normalize_rows(q).astype(np.float64) @ stored.astype(np.float64).T
+    e_r = np.linalg.norm(stored - c8 * cs[:, None], axis=1).max()
+    e_q = np.linalg.norm(o.normalize_rows(q) - q8 * qs[:, None], axis=1)
+    assert (np.abs(got[:B] - exact).max(axis=1) <= e_q * (1.01 + e_r) + 1.001 * e_r + 2e-6).all()
+    ix.close()
+
+
+@pytest.mark.parametrize(
+    "n,d,B,k,dtype",
+    [
+        (70_000, 768, 1, 10, "f32"),     # the single-query latency path
+        (70_000, 768, 32, 10, "f32"),
+        (33_000, 768, 8, 10, "f32"),
+        (20_001, 384, 17, 5, "f32"),     # ragged last tile, ragged batch
+        (60_000, 200, 5, 100, "f32"),    # d not a multiple of 128 (dpad 256), k = 100
+        (40_000, 768, 24, 10, "bf16"),
+        (12_000, 1024, 3, 10, "f16"),
+        (30_000, 64, 9, 10, "f32"),      # one 64-wide row padded to one 128-element K-step
+        (30_000, 320, 31, 10, "f32"),    # 3 int8 K-steps (dpad8 = 384)
+    ],
+)
+def test_int8_filter_path_is_exact(Index, n, d, B, k, dtype):
+    rng = np.random.default_rng(n + B)
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((B, d)).astype(np.float32)
+    ix = build8(Index, raw, dtype)
+    dist, rows = ix.search(q, k)
+    assert ix.stat("shadow8_passes") == 1 and ix.stat("shadow8_builds") == 1
+    rows_ref = o.to_storage(o.normalize_rows(raw), dtype)
+    d_ref, i_ref = o.search(rows_ref, dtype, o.normalize_rows(q), k)
+    assert np.array_equal(rows, i_ref)
+    assert np.array_equal(dist, d_ref)
+    assert ix.stat("fallback_queries") == 0, "random data must not need the fallback"
+    ix.close()
+
+
+def test_int8_shadow_follows_upserts_and_larger_batches_keep_the_bf16_filter(Index):
+    rng = np.random.default_rng(5)
+    raw = rng.standard_normal((30_000, 256)).astype(np.float32)
+    q = rng.standard_normal((4, 256)).astype(np.float32)
+    ix = build8(Index, raw)
+    ix.search(q, 10)
+    assert ix.stat("shadow8_builds") == 1
+    ix.search(q, 10)
+    assert ix.stat("shadow8_builds") == 1  # unchanged rows: no rebuild
+    # overwrite a row with the first query itself and append rows: the next search must see both
+    more = rng.standard_normal((5_000, 256)).astype(np.float32)
+    ix.upsert(np.array([123], dtype=np.int64), q[:1])
+    ix.upsert(np.arange(30_000, 35_000, dtype=np.int64), more)
+    raw[123] = q[0]
+    raw = np.concatenate([raw, more])
+    dist, rows = ix.search(q, 10)
+    assert ix.stat("shadow8_builds") == 2
+    assert rows[0, 0] == 123 and dist[0, 0] <= 2e-7
+    d_ref, i_ref = o.search(o.normalize_rows(raw), "f32", o.normalize_rows(q), 10)
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    # a batch above shadow8_max_batch takes the bf16 filter
+    ix.set_option("shadow8_max_batch", 8)
+    passes8 = ix.stat("shadow8_passes")
+    q_big = rng.standard_normal((40, 256)).astype(np.float32)
+    dist, rows = ix.search(q_big, 10)
+    assert ix.stat("shadow8_passes") == passes8
+    d_ref, i_ref = o.search(o.normalize_rows(raw), "f32", o.normalize_rows(q_big), 10)
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    ix.close()
+
+
+def test_int8_zero_query_duplicates_and_clusters_stay_exact(Index):
+    """A zero query (scale 0), exact duplicates (ties -> lower row) and a dense cluster (many candidates inside the
+    int8 slack) must all come out as the oracle says — through the fallback where the candidate lists overflow."""
+    rng = np.random.default_rng(6)
+    raw = rng.standard_normal((40_000, 128)).astype(np.float32)
+    centre = rng.standard_normal(128).astype(np.float32)
+    raw[1000:3000] = centre + 0.01 * rng.standard_normal((2000, 128)).astype(np.float32)
+    raw[20_000] = raw[7]
+    q = np.stack([np.zeros(128, dtype=np.float32), raw[7], centre, rng.standard_normal(128).astype(np.float32)])
+    ix = build8(Index, raw)
+    dist, rows = ix.search(q, 10)
+    d_ref, i_ref = o.search(o.normalize_rows(raw), "f32", o.normalize_rows(q), 10)
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    assert rows[1, 0] == 7 and rows[1, 1] == 20_000
+    ix.close()
