@@ -255,6 +255,7 @@ def main():
         if ev:
             kernels[name] = {"launches": ev, "avg_ms": ix.stat(f"time_ns:{name}") * 1e-6 / ev}
     ix.set_option("profile", 0)
+    ix_shadow8_passes = ix.stat("shadow8_passes")
     filter_stats = {key: ix.stat(key) for key in ("filter_passes", "fallback_queries", "filter_hits", "filter_survivors")}
 
     if use_dist:
@@ -286,7 +287,9 @@ def main():
     avg_launch_s = kernels[dom]["avg_ms"] * 1e-3 if dom else None
     # algorithmic bytes one launch must stream: the exact scan reads the stored rows once
     # (<= 8 queries ride along); the MFMA filter reads the bf16 shadow of the shard once for 256 queries
-    algo_bytes_launch = n_local * d * (2 if dom == "filter" else elem)
+    # (a batch of <= 8 queries is filtered through the int8 shadow: 1 B/element, rows padded to 128 elements)
+    int8_batch = dom == "filter" and B <= 8 and ix_shadow8_passes > 0
+    algo_bytes_launch = n_local * ((d + 127) // 128 * 128) if int8_batch else n_local * d * (2 if dom == "filter" else elem)
     achieved = (algo_bytes_launch / avg_launch_s / 1e9) if avg_launch_s else None
     line = {
         "metric": "queries/sec, top-10 over 10M x 768 corpus",
@@ -313,12 +316,12 @@ def main():
         "index_build_s": t_build,
         "roofline": {
             "bound": "hbm",
-            "kernel": KERNEL_NAMES.get(dom),
+            "kernel": KERNEL_NAMES.get(dom) + (" (int8 shadow)" if int8_batch else ""),
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
-            "traffic": measured_traffic(dom, args.dtype, d, n_local) if dom else None,
+            "traffic": measured_traffic("filter8" if int8_batch else dom, args.dtype, d, n_local) if dom else None,
             "algorithmic_bytes_per_launch": algo_bytes_launch,
             "avg_launch_ms": avg_launch_s * 1e3 if avg_launch_s else None,
             "launches_timed": kernels[dom]["launches"] if dom else 0,
