@@ -664,6 +664,13 @@ struct codd_knn_index : WorkBufs {
     hipStream_t shadow8_stream = nullptr;  // the stream the last rebuild ran on, and its completion
     hipEvent_t shadow8_ready = nullptr;
     int64_t stat_shadow8_builds = 0, stat_shadow8_passes = 0;
+    // the worst row's quantisation error, copied back asynchronously after every build: a corpus with badly
+    // quantisable rows (one large element, many small ones) would make the int8 bound useless and send every small batch
+    // to the exact-scan fallback, so such an index keeps the bf16 filter.  Performance only: never needed for exactness.
+    float* eps_r_host = nullptr;        // pinned
+    hipEvent_t eps_r_copied = nullptr;
+    float eps_r_known = 0.0f;
+    float shadow8_max_eps = 0.04f;
 
     // IVF (optional): rows regrouped by coarse list, original slots, list offsets, the coarse index
     codd_knn_index* coarse = nullptr;  // nlist centroids, f32
@@ -1115,6 +1122,13 @@ int ensure_shadow8(codd_knn_index* ix, hipStream_t st) {
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(ix->shadow8_ready, st));
+    if (!ix->eps_r_host) {
+        HIP_TRY(hipHostMalloc((void**)&ix->eps_r_host, sizeof(float), hipHostMallocDefault));
+        *ix->eps_r_host = 0.0f;
+        HIP_TRY(hipEventCreateWithFlags(&ix->eps_r_copied, hipEventDisableTiming));
+    }
+    HIP_TRY(hipMemcpyAsync(ix->eps_r_host, ix->eps_r_bits, sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipEventRecord(ix->eps_r_copied, st));
     ix->shadow8_stream = st;
     ix->shadow8_epoch = ix->epoch;
     ix->dirty_lo = ix->dirty_hi = 0;
@@ -1269,7 +1283,12 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
     if ((rc = ensure_buf(&ix->keys_tmp, &ix->keys_tmp_cap, (int64_t)B * k)) != 0) return rc;
     const bool use_filter = n > 0 && filter_applies(ix, B, k);
     const bool fused_prep = use_filter && B <= kTileQ;
-    const bool use8 = fused_prep && ix->shadow8_enabled && B <= ix->shadow8_max_batch && B <= 64 && CODD_MFMA16;
+    if (ix->eps_r_copied) {
+        if (hipEventQuery(ix->eps_r_copied) == hipSuccess) ix->eps_r_known = *ix->eps_r_host;
+        else (void)hipGetLastError();  // "not ready" must not surface in a later error check
+    }
+    const bool use8 = fused_prep && ix->shadow8_enabled && B <= ix->shadow8_max_batch && B <= 64 && CODD_MFMA16 &&
+                      ix->eps_r_known <= ix->shadow8_max_eps;
     if (use8) {
         if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
         if ((rc = ensure_shadow8(ix, st)) != 0) return rc;
@@ -1362,6 +1381,8 @@ int codd_knn_destroy(codd_knn_index* ix) {
     (void)hipDeviceSynchronize();
     void* bufs[] = {ix->rows, ix->shadow, ix->dstats, ix->rows_ivf, ix->ivf_ids, ix->ivf_offsets, ix->shadow8, ix->rscale, ix->eps_r_bits};
     if (ix->shadow8_ready) (void)hipEventDestroy(ix->shadow8_ready);
+    if (ix->eps_r_copied) (void)hipEventDestroy(ix->eps_r_copied);
+    if (ix->eps_r_host) (void)hipHostFree(ix->eps_r_host);
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     for (WorkSlot& w : ix->slots) {
@@ -1754,6 +1775,13 @@ int codd_knn_get_stat(const codd_knn_index* ix, const char* key, int64_t* out) {
     else if (strcmp(key, "filter_passes") == 0) *out = ix->stat_filter_passes;
     else if (strcmp(key, "shadow8_builds") == 0) *out = ix->stat_shadow8_builds;
     else if (strcmp(key, "shadow8_passes") == 0) *out = ix->stat_shadow8_passes;
+    else if (strcmp(key, "shadow8_eps_r_micro") == 0) {  // worst row's quantisation error norm x 1e6, as last read back
+        if (ix->eps_r_copied && hipEventQuery(ix->eps_r_copied) == hipSuccess) *out = (int64_t)(*ix->eps_r_host * 1e6f);
+        else {
+            (void)hipGetLastError();
+            *out = (int64_t)(ix->eps_r_known * 1e6f);
+        }
+    }
     else if (strcmp(key, "fallback_queries") == 0 || strcmp(key, "filter_hits") == 0 || strcmp(key, "filter_survivors") == 0) {
         // device-side counters (the search itself never reads them back): synchronises
         unsigned long long h[4] = {0, 0, 0, 0};

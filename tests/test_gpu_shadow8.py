@@ -147,3 +147,26 @@ def test_int8_zero_query_duplicates_and_clusters_stay_exact(Index):
     assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
     assert rows[1, 0] == 7 and rows[1, 1] == 20_000
     ix.close()
+
+
+def test_badly_quantisable_rows_turn_the_int8_filter_off_not_wrong(Index):
+    """One large element and many small ones: int8 rounds the small ones away, the worst-row error norm is large and the
+    int8 bound useless.  The first search still answers exactly (through the fallback if need be); once the error
+    norm has been read back the index keeps the bf16 filter for small batches."""
+    import torch
+
+    rng = np.random.default_rng(8)
+    raw = rng.standard_normal((30_000, 512)).astype(np.float32)
+    raw[:2000, 0] = 40.0  # after normalisation: one element ~0.87, the others ~0.02 = 2-3 int8 steps
+    q = rng.standard_normal((3, 512)).astype(np.float32)
+    ix = build8(Index, raw)
+    d_ref, i_ref = o.search(o.normalize_rows(raw), "f32", o.normalize_rows(q), 10)
+    dist, rows = ix.search(q, 10)
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    torch.cuda.synchronize()
+    assert ix.stat("shadow8_eps_r_micro") > 40_000
+    passes8 = ix.stat("shadow8_passes")
+    dist, rows = ix.search(q, 10)
+    assert ix.stat("shadow8_passes") == passes8, "the index should have gone back to the bf16 filter"
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    ix.close()
