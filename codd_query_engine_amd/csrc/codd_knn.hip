@@ -430,7 +430,8 @@ __global__ __launch_bounds__(256) void shadow8_from_rows_kernel(const void* __re
 // is exact and the two scale multiplications cost < 4e-7)
 __global__ __launch_bounds__(256) void prep_queries8_kernel(const float* __restrict__ in, int B, int d, int dpad, int dpad8,
                                                             float* __restrict__ qn, uint32_t* __restrict__ qfrag8, float* __restrict__ qmeta,
-                                                            const unsigned* __restrict__ eps_r_bits, unsigned* __restrict__ ctl, int ctl_words) {
+                                                            const unsigned* __restrict__ eps_r_bits, unsigned* __restrict__ ctl, int ctl_words,
+                                                            float slack_scale) {
     const int lane = lane_id();
     const int q = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     for (int i = (int)blockIdx.x * 256 + (int)threadIdx.x; i < ctl_words; i += (int)gridDim.x * 256) ctl[i] = 0u;
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(256) void prep_queries8_kernel(const float* __restr
     if (lane == 0) {
         const float eq = __builtin_sqrtf(err2) * 1.0001f + 1e-7f, er = __uint_as_float(*eps_r_bits);
         qmeta[q] = scale;
-        qmeta[256 + q] = 2.0f * (eq * (1.01f + er) + 1.001f * er + 2e-6f);
+        qmeta[256 + q] = slack_scale * 2.0f * (eq * (1.01f + er) + 1.001f * er + 2e-6f);
     }
 }
 
@@ -607,7 +608,7 @@ struct WorkBufs {
     u64* keys_tmp = nullptr;   int64_t keys_tmp_cap = 0;  // [B][k]
     uint4* qfrag = nullptr;    int64_t qfrag_cap = 0;     // pieces
     float* thr = nullptr;                                  // [256]
-    float* bucket_max = nullptr; int64_t bucket_cap = 0;   // [sample tiles][256]
+    u64* bucket_max = nullptr; int64_t bucket_cap = 0;     // [256][sample tiles] best (score, row) key per sampled tile
     u64* hits = nullptr;       int64_t hits_cap = 0;      // [256][hit_cap_q]
     FilterCtl* ctl = nullptr;                              // device
     u64* fb_partial = nullptr; int64_t fb_partial_cap = 0; // [256][blocks][k] partials of the fallback scan
@@ -653,7 +654,7 @@ struct codd_knn_index : WorkBufs {
 
     // int8 shadow for small batches (optional; rebuilt lazily from the stored rows when they have changed)
     int shadow8_enabled = 1;
-    int shadow8_max_batch = 8;    // batches up to this size take the int8 filter (beyond, its candidate volume costs more than the bytes save)
+    int shadow8_max_batch = 256;  // batches up to this size (one query pass) take the int8 filter
     int sample_div8 = 20;         // its thresholds come from a larger sample (the int8 slack is ~5x the bf16 one)
     uint4* shadow8 = nullptr;
     int64_t shadow8_rows = 0;     // rows the allocation covers (multiple of 256)
@@ -671,6 +672,7 @@ struct codd_knn_index : WorkBufs {
     hipEvent_t eps_r_copied = nullptr;
     float eps_r_known = 0.0f;
     float shadow8_max_eps = 0.04f;
+    float exp_slack_scale = 1.0f;  // diagnostic only ("exp_slack_pct"): < 1 makes the int8 filter UNSOUND; what-if timing
 
     // IVF (optional): rows regrouped by coarse list, original slots, list offsets, the coarse index
     codd_knn_index* coarse = nullptr;  // nlist centroids, f32
@@ -1032,7 +1034,7 @@ int launch_finalize(int niter, int slots, int B, hipStream_t st, const codd_knn_
 }
 
 size_t filter_lds_bytes(int mode) {
-    return (size_t)kLdsQBytes + 320 * 4 + (mode == MODE_FILTER ? (size_t)kHitCap * 12 : 0);
+    return (size_t)kLdsQBytes + kLdsWords * 4 + (mode == MODE_FILTER ? (size_t)kHitCap * 12 : 0);
 }
 
 int ensure_filter_workspace(codd_knn_index* ix) {
@@ -1172,7 +1174,12 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     hipLaunchKernelGGL((gemm_filter_kernel<MODE_SAMPLE, NBQ, 1>), g, b, lds, st, shadow, qfrag, n, nsteps, ts, stride, \
                        nullptr, ix->bucket_max, nullptr, nullptr, 0, nullptr, nullptr, ix->rscale, ix->qmeta)
         if (use8) {
-            if (nbq == 1) CODD_LAUNCH_SAMPLE8(1); else CODD_LAUNCH_SAMPLE8(2);
+            switch (nbq) {
+                case 1: CODD_LAUNCH_SAMPLE8(1); break;
+                case 2: CODD_LAUNCH_SAMPLE8(2); break;
+                case 4: CODD_LAUNCH_SAMPLE8(4); break;
+                default: CODD_LAUNCH_SAMPLE8(8); break;
+            }
         } else
         switch (nbq) {
             case 1: CODD_LAUNCH_SAMPLE(1); break;
@@ -1184,10 +1191,26 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
 #undef CODD_LAUNCH_SAMPLE8
     }
     HIP_TRY(hipGetLastError());
-    if (slots == 1)
-        hipLaunchKernelGGL(select_thr_kernel<1>, dim3(kTileQ), dim3(64), 0, st, ix->bucket_max, ts, nq, k, 2.0f * eps, ix->thr, slack_q);
-    else
-        hipLaunchKernelGGL(select_thr_kernel<2>, dim3(kTileQ), dim3(64), 0, st, ix->bucket_max, ts, nq, k, 2.0f * eps, ix->thr, slack_q);
+    {
+        // thresholds anchored on the exact scores of the k best sampled rows (anchor_thr_kernel)
+        const int nch_t = ix->dpad / elems_per_chunk(ix->dtype);
+        const int niter_t = (nch_t + kWave - 1) / kWave;
+#define CODD_ANCHOR(DT, NI, SL)                                                                                                       \
+    hipLaunchKernelGGL((anchor_thr_kernel<DT, NI, SL>), dim3(kTileQ), dim3(64), 0, st, ix->bucket_max, ts, nq, k, ix->rows, ix->dpad, qn, \
+                       eps, slack_q, ix->thr)
+#define CODD_ANCHOR_NI(DT, SL)                                \
+    switch (niter_t) {                                         \
+        case 1: CODD_ANCHOR(DT, 1, SL); break;                 \
+        case 2: CODD_ANCHOR(DT, 2, SL); break;                 \
+        case 3: CODD_ANCHOR(DT, 3, SL); break;                 \
+        default: CODD_ANCHOR(DT, 4, SL); break;                \
+    }
+        if (ix->dtype == DT_F32) { if (slots == 1) { CODD_ANCHOR_NI(DT_F32, 1) } else { CODD_ANCHOR_NI(DT_F32, 2) } }
+        else if (ix->dtype == DT_BF16) { if (slots == 1) { CODD_ANCHOR_NI(DT_BF16, 1) } else { CODD_ANCHOR_NI(DT_BF16, 2) } }
+        else { if (slots == 1) { CODD_ANCHOR_NI(DT_F16, 1) } else { CODD_ANCHOR_NI(DT_F16, 2) } }
+#undef CODD_ANCHOR_NI
+#undef CODD_ANCHOR
+    }
     HIP_TRY(hipGetLastError());
     {
         EvScope ev(ix, EV_FILTER, st);
@@ -1200,7 +1223,12 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     hipLaunchKernelGGL((gemm_filter_kernel<MODE_FILTER, NBQ, 1>), g, b, lds, st, shadow, qfrag, n, nsteps, ntiles,  \
                        (int64_t)1, ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, nullptr, ix->rscale, ix->qmeta)
         if (use8) {
-            if (nbq == 1) CODD_LAUNCH_FILTER8(1); else CODD_LAUNCH_FILTER8(2);
+            switch (nbq) {
+                case 1: CODD_LAUNCH_FILTER8(1); break;
+                case 2: CODD_LAUNCH_FILTER8(2); break;
+                case 4: CODD_LAUNCH_FILTER8(4); break;
+                default: CODD_LAUNCH_FILTER8(8); break;
+            }
         } else
         switch (nbq) {
             case 1: CODD_LAUNCH_FILTER(1); break;
@@ -1216,7 +1244,7 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     const int niter = (nchunks + kWave - 1) / kWave;
     // the int8 filter leaves thousands of survivors per query and is only used for a handful of queries: share each
     // query's re-scoring out between several workgroups, then merge their lists
-    const int nparts = use8 ? (nq <= 8 ? 16 : 8) : 1;
+    const int nparts = use8 ? (nq <= 8 ? 16 : (nq <= 32 ? 8 : (nq <= 64 ? 4 : 1))) : 1;
     if (nparts > 1 && (rc = ensure_buf(&ix->partial, &ix->partial_cap, (int64_t)nq * nparts * k)) != 0) return rc;
     {
         EvScope ev(ix, EV_FINALIZE, st);
@@ -1287,7 +1315,7 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
         if (hipEventQuery(ix->eps_r_copied) == hipSuccess) ix->eps_r_known = *ix->eps_r_host;
         else (void)hipGetLastError();  // "not ready" must not surface in a later error check
     }
-    const bool use8 = fused_prep && ix->shadow8_enabled && B <= ix->shadow8_max_batch && B <= 64 && CODD_MFMA16 &&
+    const bool use8 = fused_prep && ix->shadow8_enabled && B <= ix->shadow8_max_batch && CODD_MFMA16 &&
                       ix->eps_r_known <= ix->shadow8_max_eps;
     if (use8) {
         if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
@@ -1297,7 +1325,7 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
         if (!ix->qmeta) HIP_TRY(hipMalloc((void**)&ix->qmeta, 512 * sizeof(float)));
         hipLaunchKernelGGL(prep_queries8_kernel, dim3(kTileQ / 4), dim3(256), 0, st, dev_queries, B, ix->dim, ix->dpad, dpad8, ix->qn,
                            reinterpret_cast<uint32_t*>(ix->qfrag8), ix->qmeta, ix->eps_r_bits, reinterpret_cast<unsigned*>(ix->ctl),
-                           (int)(sizeof(FilterCtl) / 4));
+                           (int)(sizeof(FilterCtl) / 4), ix->exp_slack_scale);
         HIP_TRY(hipGetLastError());
     } else if (fused_prep) {
         if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
@@ -1566,7 +1594,7 @@ int codd_knn_approx_scores(codd_knn_index* ix, const float* dev_queries, int B, 
         if (!ix->qmeta) HIP_TRY(hipMalloc((void**)&ix->qmeta, 512 * sizeof(float)));
         hipLaunchKernelGGL(prep_queries8_kernel, dim3(kTileQ / 4), dim3(256), 0, st, dev_queries, B, ix->dim, ix->dpad, dpad8, ix->qn,
                            reinterpret_cast<uint32_t*>(ix->qfrag8), ix->qmeta, ix->eps_r_bits, reinterpret_cast<unsigned*>(ix->ctl),
-                           (int)(sizeof(FilterCtl) / 4));
+                           (int)(sizeof(FilterCtl) / 4), 1.0f);
         const int64_t ntiles8 = (ix->count + kTileRows - 1) / kTileRows;
         const int64_t g8 = ntiles8 < ix->num_cus ? ntiles8 : ix->num_cus;
         hipLaunchKernelGGL((gemm_filter_kernel<MODE_DUMP, 1, 1>), dim3((unsigned)g8), dim3(kFilterThreads), filter_lds_bytes(MODE_DUMP), st,
@@ -1702,8 +1730,13 @@ int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {
         return CODD_KNN_OK;
     }
     if (strcmp(key, "shadow8_max_batch") == 0) {
-        if (value < 1 || value > 64) return fail(CODD_KNN_EINVAL, "shadow8_max_batch must be in [1,64]%s");
+        if (value < 1 || value > 256) return fail(CODD_KNN_EINVAL, "shadow8_max_batch must be in [1,256]%s");
         ix->shadow8_max_batch = (int)value;
+        return CODD_KNN_OK;
+    }
+    if (strcmp(key, "exp_slack_pct") == 0) {  // diagnostic: see exp_slack_scale
+        if (value < 1 || value > 100) return fail(CODD_KNN_EINVAL, "exp_slack_pct must be in [1,100]%s");
+        ix->exp_slack_scale = (float)value / 100.0f;
         return CODD_KNN_OK;
     }
     if (strcmp(key, "sample_div8") == 0) {
@@ -1798,7 +1831,7 @@ int codd_knn_get_stat(const codd_knn_index* ix, const char* key, int64_t* out) {
         int64_t b = ix->capacity * (int64_t)ix->dpad * (int64_t)elem_size(ix->dtype) + ix->shadow_rows * (int64_t)ix->dpad * 2 +
                     ix->shadow8_rows * ((int64_t)dpad8_of(ix) + 4);
         for (const WorkSlot& w : ix->slots)
-            b += w.bufs.qn_cap * 4 + w.bufs.partial_cap * 8 + w.bufs.keys_tmp_cap * 8 + w.bufs.hits_cap * 8 + w.bufs.bucket_cap * 4 +
+            b += w.bufs.qn_cap * 4 + w.bufs.partial_cap * 8 + w.bufs.keys_tmp_cap * 8 + w.bufs.hits_cap * 8 + w.bufs.bucket_cap * 8 +
                  w.bufs.qfrag_cap * 16 + w.bufs.fb_partial_cap * 8 + w.bufs.probe_cap * 8 + w.bufs.ivf_partial_cap * 8;
         *out = b;
     } else if (strcmp(key, "workspaces") == 0) {

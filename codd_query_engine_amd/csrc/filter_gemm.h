@@ -153,6 +153,7 @@ constexpr int kRing = CODD_RING;        // corpus-fragment register ring (K-step
 constexpr int kPrefetch = CODD_RING - 1;  // K-steps the corpus loads run ahead
 
 enum { MODE_FILTER = 0, MODE_SAMPLE = 1, MODE_DUMP = 2 };
+constexpr int kLdsWords = 576;  // dwords of per-workgroup bookkeeping behind the query slices (256 thresholds + counter, or 256 u64 keys)
 
 // flags[] words shared with the host
 enum { FLAG_WG_OVERFLOW = 0 /* statistics: a workgroup hit list filled up */, FLAG_NEED_FALLBACK = 1 /* any query queued */, FLAG_WORDS = 4 };
@@ -276,7 +277,7 @@ __device__ __forceinline__ void flush_hits_binned(const unsigned* lds_hits, unsi
 // gemm_filter_kernel<MODE, NBQ>   (NBQ = 32-query blocks actually multiplied: 1, 2, 4 or 8; a small
 //   batch pays only for its own MFMAs and LDS traffic and the kernel turns into a pure HBM stream)
 //   MODE_FILTER: every (query, row) with approx score >= thr[query] is appended to hits[query][]
-//   MODE_SAMPLE: per (tile, query) the maximum approx score is written to bucket_max[query][tile]
+//   MODE_SAMPLE: per (tile, query) the best (approx score, row) key is written to bucket_key[query][tile]
 //   MODE_DUMP  : all scores to dump[query][row] (diagnostics / layout tests, small n only)
 // Run-tile u (0 <= u < ntiles_run) is corpus tile u*tile_stride; workgroup b takes u = b, b+G, ...
 // ---------------------------------------------------------------------------------------------
@@ -286,7 +287,7 @@ __device__ __forceinline__ void flush_hits_binned(const unsigned* lds_hits, unsi
 template <int MODE, int NBQ, int EL = 0>
 __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gemm_filter_kernel(
     const uint4* __restrict__ shadow, const uint4* __restrict__ qfrag, int64_t n, int nsteps, int64_t ntiles_run,
-    int64_t tile_stride, const float* __restrict__ thr, float* __restrict__ bucket_max, u64* __restrict__ hits,
+    int64_t tile_stride, const float* __restrict__ thr, u64* __restrict__ bucket_key, u64* __restrict__ hits,
     unsigned* __restrict__ hit_cnt, int cap_q, unsigned* __restrict__ flags, float* __restrict__ dump,
     const float* __restrict__ rscale = nullptr, const float* __restrict__ qscale = nullptr) {
     static_assert(EL == 0 || (CODD_MFMA16 && kKS == 2), "the int8 mode is written for the 16x16 MFMA geometry");
@@ -295,7 +296,8 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint4* ldsQ = reinterpret_cast<uint4*>(smem);                        // 2 stages x kQS slices x 32 KiB
     unsigned* lds_w = reinterpret_cast<unsigned*>(smem + kLdsQBytes);    // [0..255] thr / bucket max, [256] hit count
-    unsigned* lds_hits = lds_w + 320;                                    // kHitCap x 3 dwords (FILTER only)
+    unsigned* lds_hits = lds_w + kLdsWords;                              // kHitCap x 3 dwords (FILTER only)
+    u64* lds_k = reinterpret_cast<u64*>(lds_w);                          // SAMPLE: [0..255] best (score, row) key of the tile per query
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = kQSplit == 1 ? wave : wave % kRowGroups;  // row group of the tile this wave owns
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
         if (tid < 256) lds_w[tid] = __float_as_uint(EL ? thr[tid] / qscale[tid] : thr[tid]);
         if (tid == 0) lds_w[256] = 0u;
     } else if (MODE == MODE_SAMPLE) {
-        if (tid < 256) lds_w[tid] = 0u;
+        if (tid < 256) lds_k[tid] = 0ull;
     }
 
     constexpr int kSP = NBQ * 256;  // 16-byte pieces of a query slice that are actually staged
@@ -527,14 +529,16 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                 } else if (MODE == MODE_SAMPLE) {
 #pragma unroll
                     for (int qb = 0; qb < NQB; ++qb) {
-                        float m = -INFINITY;
+                        u64 best = 0ull;  // this lane's best (score, row) of the block; ties -> lower row, as everywhere
 #pragma unroll
                         for (int r = 0; r < kAccRegs; ++r) {
                             const int64_t row = row0 + acc_row(r, lane);
-                            const float v = (!ragged || row < n) ? (EL ? (float)acc[rs][qb][r] * rsc[r] : (float)acc[rs][qb][r]) : -INFINITY;
-                            m = fmaxf(m, v);
+                            if (!ragged || row < n) {
+                                const u64 key = make_key(EL ? (float)acc[rs][qb][r] * rsc[r] : (float)acc[rs][qb][r], (uint32_t)row);
+                                best = key > best ? key : best;
+                            }
                         }
-                        atomicMax(&lds_w[qbase + qb * kMB], ord_f32(m));
+                        atomicMax(reinterpret_cast<unsigned long long*>(&lds_k[qbase + qb * kMB]), (unsigned long long)best);
                     }
                 } else {
 #pragma unroll
@@ -694,9 +698,12 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                     // all 8 waves have folded this tile into lds_w: publish, reset, and fence the reset
                     // against the next tile's fold
                     if (tid < 256) {
-                        // [query][bucket]: select_thr reads rows.  (int8: the fold ran on acc * rscale; scale >= 0 keeps the order)
-                        bucket_max[(int64_t)tid * ntiles_run + w_u] = EL ? unord_f32(lds_w[tid]) * qscale[tid] : unord_f32(lds_w[tid]);
-                        lds_w[tid] = 0u;
+                        // [query][bucket]: the threshold kernel reads rows of it.  (int8: the fold ran on acc * rscale; a
+                        // scale >= 0 keeps the order, the query's scale is applied here)
+                        u64 key = lds_k[tid];
+                        if (EL && key) key = make_key(key_score(key) * qscale[tid], key_row(key));
+                        bucket_key[(int64_t)tid * ntiles_run + w_u] = key;
+                        lds_k[tid] = 0ull;
                     }
                     __syncthreads();
                 }
@@ -719,38 +726,6 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// select_thr_kernel: one wave per query.  thr[q] = (k-th largest bucket maximum) - slack, a score
-// every true top-k row's approximation provably clears; -inf when fewer than k buckets exist;
-// +inf for padding queries (q >= B) so they never hit.
-// ---------------------------------------------------------------------------------------------
-template <int SLOTS>
-__global__ __launch_bounds__(64) void select_thr_kernel(const float* __restrict__ bucket_max, int64_t nbuckets, int B, int k,
-                                                        float slack, float* __restrict__ thr, const float* __restrict__ slack_q = nullptr) {
-    const int q = blockIdx.x, lane = lane_id();
-    if (q >= B) {
-        if (lane == 0) thr[q] = INFINITY;
-        return;
-    }
-    WaveTopK<SLOTS> L;
-    L.init();
-    for (int64_t i0 = 0; i0 < nbuckets; i0 += kWave) {
-        const int64_t i = i0 + lane;
-        const u64 cand = i < nbuckets ? make_key(bucket_max[(int64_t)q * nbuckets + i], (uint32_t)i) : 0ull;
-        L.offer_lanes(cand, k, lane);
-    }
-    if (lane == 0) thr[q] = L.thr ? key_score(L.thr) - (slack_q ? slack_q[q] : slack) : -INFINITY;  // (int8: the slack is per query)
-}
-
-// ---------------------------------------------------------------------------------------------
-// finalize_kernel<DT, NITER, SLOTS>: one workgroup (4 waves) per query.
-//   1. a_k = k-th largest APPROXIMATE score among the query's hits;
-//   2. survivors = hits with approx >= a_k - 2*eps  (no other row can reach the exact top-k);
-//   3. exact canonical fp32 score of every survivor (one wave per row, same expression as the scan);
-//   4. top-k of the exact keys -> out_keys[q] (global rows: row_base added).
-// A query whose global hit list overflowed (more than cap_q candidates) is queued for the exact-scan
-// fallback instead: fb_list[atomicAdd(fb_count)] = q.
-// ---------------------------------------------------------------------------------------------
 constexpr int kSurvChunk = 2048;  // hits examined per round; their survivors always fit the LDS list
 
 template <int DT, int NITER, int SLOTS>
@@ -770,6 +745,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
     __shared__ unsigned lds_surv[kSurvChunk];
     __shared__ unsigned lds_n;
     __shared__ float lds_lo;
+    __shared__ float lds_anchor[4];
 
     const int q = blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned total = hit_cnt[q * kHitCntStride];
@@ -811,12 +787,70 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
                 if (s * kWave + lane >= k) cand = 0ull;
                 L.offer_lanes(cand, k, lane);
             }
-        if (lane == 0) lds_lo = L.thr ? key_score(L.thr) - (two_eps_q ? two_eps_q[blockIdx.x] : two_eps) : -INFINITY;
+        // rows of the k best approximate hits (or none when the list is not full: then every hit survives)
+        if (lane == 0) lds_n = L.thr ? (unsigned)k : 0u;
+        if (L.thr) {
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s)
+                if (s * kWave + lane < k) lds_surv[s * kWave + lane] = key_row(L.v[s]);
+        }
     }
     __syncthreads();
+    const uint4* base = reinterpret_cast<const uint4*>(rows_);
+    // canonical exact scores of up to four rows per wave step (the expression of the exact scan)
+    auto rescore4 = [&](const unsigned (&rowid)[4], float (&sc)[4]) __attribute__((always_inline)) {
+        float w[4][NITER][E];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint4* p = base + (int64_t)rowid[r] * nchunks + lane;
+#pragma unroll
+            for (int it = 0; it < NITER; ++it) {
+                uint4 cch = make_uint4(0u, 0u, 0u, 0u);
+                if (lane + kWave * it < nchunks) cch = p[kWave * it];
+                RT::widen(cch, w[r][it]);
+            }
+        }
+        float a[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int it = 0; it < NITER; ++it)
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc = __builtin_fmaf(qf[it][e], w[r][it][e], acc);
+            a[r] = acc;
+        }
+        const float y = butterfly_sum4(a[0], a[1], a[2], a[3], lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[r] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(y), 16 * r));
+    };
+    // 1b. anchor: those k rows are k distinct rows with EXACT scores >= L' := their smallest exact score, so the true
+    // k-th best score is >= L' and every true top-k row has an approximate score >= L' - eps (one eps, not two: the
+    // bound compares an approximation with an exact score, not two approximations)
+    {
+        const unsigned nk = lds_n;
+        float worst = INFINITY;
+        for (unsigned j = wave * 4; j < nk; j += 16) {
+            unsigned rowid[4];
+            float sc[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rowid[r] = lds_surv[j + r < nk ? j + r : nk - 1];
+            rescore4(rowid, sc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (j + r < nk) worst = fminf(worst, sc[r]);
+        }
+        if (lane == 0) lds_anchor[wave] = worst;
+        __syncthreads();
+        if (tid == 0) {
+            const float eps1 = 0.5f * (two_eps_q ? two_eps_q[blockIdx.x] : two_eps);
+            const float l4 = fminf(fminf(lds_anchor[0], lds_anchor[1]), fminf(lds_anchor[2], lds_anchor[3]));
+            lds_lo = nk ? l4 - eps1 : -INFINITY;
+        }
+        __syncthreads();
+    }
     const float lo = lds_lo;
 
-    const uint4* base = reinterpret_cast<const uint4*>(rows_);
     WaveTopK<SLOTS> X;
     X.init();
     unsigned survivors = 0;
@@ -837,33 +871,14 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
         const unsigned ns = lds_n;
         survivors += ns;
         for (unsigned j = wave * 4; j < ns; j += 16) {
-            float w[4][NITER][E];
             unsigned rowid[4];
+            float sc4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rowid[r] = lds_surv[j + r < ns ? j + r : ns - 1];
+            rescore4(rowid, sc4);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                rowid[r] = lds_surv[j + r < ns ? j + r : ns - 1];
-                const uint4* p = base + (int64_t)rowid[r] * nchunks + lane;
-#pragma unroll
-                for (int it = 0; it < NITER; ++it) {
-                    uint4 cch = make_uint4(0u, 0u, 0u, 0u);
-                    if (lane + kWave * it < nchunks) cch = p[kWave * it];
-                    RT::widen(cch, w[r][it]);
-                }
-            }
-            float a[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int it = 0; it < NITER; ++it)
-#pragma unroll
-                    for (int e = 0; e < E; ++e) acc = __builtin_fmaf(qf[it][e], w[r][it][e], acc);
-                a[r] = acc;
-            }
-            const float y = butterfly_sum4(a[0], a[1], a[2], a[3], lane);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(y), 16 * r));
+                const float sc = sc4[r];
                 if (j + r < ns) X.offer(make_key(sc, row_base + rowid[r]), k, lane);
             }
         }
@@ -891,6 +906,79 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
         const int rank = s * kWave + lane;
         if (rank < k) (nparts > 1 ? part_keys + ((int64_t)q * nparts + part) * k : out_keys + (int64_t)q * k)[rank] = X.v[s];
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// anchor_thr_kernel: one wave per query.  The sample pass left, per bucket (sampled tile), the (approximate score, row)
+// key of its best row.  The k best buckets name k DISTINCT rows; their EXACT scores (canonical expression) are all
+// >= L := the smallest of them, hence the true k-th best score is >= L and every true top-k row has an approximate
+// score >= L - eps.  thr[q] = L - eps(q); -inf when fewer than k buckets hold a row; +inf for padding queries.
+// (Anchoring on exact scores costs k row reads per query and saves one eps of slack against the k-th largest
+// *approximate* bucket maximum: a third fewer hits for the bf16 filter, 6x fewer for the int8 one.)
+// ---------------------------------------------------------------------------------------------
+template <int DT, int NITER, int SLOTS>
+__global__ __launch_bounds__(64) void anchor_thr_kernel(const u64* __restrict__ bucket_key, int64_t nbuckets, int B, int k,
+                                                        const void* __restrict__ rows_, int dpad, const float* __restrict__ qn, float eps,
+                                                        const float* __restrict__ two_eps_q, float* __restrict__ thr) {
+    typedef RowTraits<DT> RT;
+    constexpr int E = RT::E;
+    const int q = blockIdx.x, lane = lane_id();
+    if (q >= B) {
+        if (lane == 0) thr[q] = INFINITY;
+        return;
+    }
+    const int nchunks = dpad / E;
+    float qf[NITER][E];
+#pragma unroll
+    for (int it = 0; it < NITER; ++it) {
+        const int j = lane + kWave * it;
+#pragma unroll
+        for (int e = 0; e < E; ++e) qf[it][e] = j < nchunks ? qn[(int64_t)q * dpad + (int64_t)j * E + e] : 0.0f;
+    }
+    WaveTopK<SLOTS> L;
+    L.init();
+    for (int64_t i0 = 0; i0 < nbuckets; i0 += kWave) {
+        const int64_t i = i0 + lane;
+        L.offer_lanes(i < nbuckets ? bucket_key[(int64_t)q * nbuckets + i] : 0ull, k, lane);
+    }
+    if (!L.thr) {  // fewer than k buckets with a row: no threshold can be justified
+        if (lane == 0) thr[q] = -INFINITY;
+        return;
+    }
+    const uint4* base = reinterpret_cast<const uint4*>(rows_);
+    float worst = INFINITY;
+    for (int j = 0; j < k; j += 4) {
+        float w[4][NITER][E];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rank = j + r < k ? j + r : k - 1;  // uniform
+            const u64 key = SLOTS == 1 || rank < kWave ? readlane_u64(L.v[0], rank & (kWave - 1)) : readlane_u64(L.v[SLOTS - 1], rank & (kWave - 1));
+            const uint4* p = base + (int64_t)key_row(key) * nchunks + lane;
+#pragma unroll
+            for (int it = 0; it < NITER; ++it) {
+                uint4 cch = make_uint4(0u, 0u, 0u, 0u);
+                if (lane + kWave * it < nchunks) cch = p[kWave * it];
+                RT::widen(cch, w[r][it]);
+            }
+        }
+        float a[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int it = 0; it < NITER; ++it)
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc = __builtin_fmaf(qf[it][e], w[r][it][e], acc);
+            a[r] = acc;
+        }
+        const float y = butterfly_sum4(a[0], a[1], a[2], a[3], lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(y), 16 * r));
+            if (j + r < k) worst = fminf(worst, sc);
+        }
+    }
+    if (lane == 0) thr[q] = worst - (two_eps_q ? 0.5f * two_eps_q[q] : eps);
 }
 
 }  // namespace codd

@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "base": {},
-    "stagger": {"CODD_STAGGER": 1},
+    "ballot": {"CODD_BALLOT_HITS": 1},
 }
 
 
@@ -47,6 +47,7 @@ def child(rows, rounds):
         m = min(250_000, rows - c0)
         ix.upsert_device(c0, torch.randn((m, d), generator=g, device="cuda"))
     q = torch.randn((B, d), generator=g, device="cuda")
+    ix.set_option("shadow8", 0)  # the first set of timings is the bf16 filter; CODD_EXP_INT8=1 adds the int8 one
     dist, idx = ix.search_tensors(q, k)
     torch.cuda.synchronize()
     ix.set_option("filter", 0)
@@ -61,6 +62,18 @@ def child(rows, rounds):
     for name in ("filter", "sample", "finalize"):
         ev = ix.stat(f"events:{name}")
         out[name] = ix.stat(f"time_ns:{name}") * 1e-6 / max(ev, 1)
+    if os.environ.get("CODD_EXP_INT8"):
+        ix.set_option("shadow8", 1)
+        ix.set_option("shadow8_max_batch", 256)
+        ix.search_tensors(q, k)
+        torch.cuda.synchronize()
+        ix.set_option("profile", rounds * 4 + 8)
+        for _ in range(rounds):
+            ix.search_tensors(q, k)
+        torch.cuda.synchronize()
+        ev = ix.stat("events:filter")
+        out["filter_int8"] = ix.stat("time_ns:filter") * 1e-6 / max(ev, 1)
+        out["passes8"] = ix.stat("shadow8_passes")
     print(json.dumps(out))
 
 
@@ -79,6 +92,9 @@ def run(rows):
     for n in names:
         r = results[n]
         if r:
+            if "filter_int8" in r[0]:
+                m8 = sorted(x["filter_int8"] for x in r)
+                print(f"{n:12s} int8 filter ms min {m8[0]:.3f} med {m8[len(m8)//2]:.3f} passes8={r[0]['passes8']}", flush=True)
             ms = sorted(x["filter"] for x in r)
             print(f"{n:12s} filter ms min {ms[0]:.3f} med {ms[len(ms)//2]:.3f}  sample {r[0]['sample']:.3f} finalize {r[0]['finalize']:.3f} ok={all(x['ok'] for x in r)} fb={r[0]['fallback']}", flush=True)
 
