@@ -1066,8 +1066,16 @@ int ensure_filter_workspace(codd_knn_index* ix) {
 // how many evenly spaced tiles set the thresholds: ~ntiles/sample_div (so the sample costs a fixed
 // fraction of the main pass at every shard size and the hit volume per query stays ~k*sample_div),
 // at least max(64, 4k) where the corpus has that many tiles, at most sample_tiles
-int64_t sample_tile_count(const codd_knn_index* ix, int64_t ntiles, int k, bool use8 = false) {
-    int64_t ts = ntiles / (use8 ? ix->sample_div8 : ix->sample_div);
+int64_t sample_tile_count(const codd_knn_index* ix, int64_t ntiles, int k, bool use8 = false, int nbq = 8) {
+    int64_t ts = ntiles / (use8 ? (nbq == 1 ? 2 * ix->sample_div8 : ix->sample_div8) : ix->sample_div);
+    if (use8) {
+        // the int8 filter pays more per hit (wider slack, more of them) and less per sampled tile: three rounds of
+        // workgroups where that is still under a quarter of the corpus (scripts/int8_sweep.py: 1/6 of a 1.25M-row
+        // shard, 1/20 of 10M rows; twice as sparse for <= 32 queries, whose sample is a pure byte stream)
+        const int64_t rounds = (nbq == 1 ? 1 : 3) * (int64_t)ix->num_cus;
+        const int64_t floor8 = rounds < ntiles / 4 ? rounds : ntiles / 4;
+        if (ts < floor8) ts = floor8;
+    }
     const int64_t lo = 4 * (int64_t)k > 64 ? 4 * (int64_t)k : 64;
     if (ts < lo) ts = lo;
     // a sample of fewer tiles than there are CUs takes as long as one full round of workgroups (one tile each), and a
@@ -1160,9 +1168,9 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     }
 
     // sample: every `stride`-th tile
-    const int64_t ts = sample_tile_count(ix, ntiles, k, use8);
-    const int64_t stride = ntiles / ts;
     const int nbq = nq <= 32 ? 1 : (nq <= 64 ? 2 : (nq <= 128 ? 4 : 8));  // 32-query blocks the GEMM multiplies
+    const int64_t ts = sample_tile_count(ix, ntiles, k, use8, nbq);
+    const int64_t stride = ntiles / ts;
     {
         EvScope ev(ix, EV_SAMPLE, st);
         const dim3 g((unsigned)(ts < ix->num_cus ? ts : ix->num_cus)), b(kFilterThreads);
