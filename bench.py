@@ -287,8 +287,8 @@ def main():
     avg_launch_s = kernels[dom]["avg_ms"] * 1e-3 if dom else None
     # algorithmic bytes one launch must stream: the exact scan reads the stored rows once
     # (<= 8 queries ride along); the MFMA filter reads the bf16 shadow of the shard once for 256 queries
-    # (a batch of <= 8 queries is filtered through the int8 shadow: 1 B/element, rows padded to 128 elements)
-    int8_batch = dom == "filter" and B <= 8 and ix_shadow8_passes > 0
+    # (a batch of <= 256 queries is filtered through the int8 shadow: 1 B/element, rows padded to 128 elements)
+    int8_batch = dom == "filter" and B <= 256 and ix_shadow8_passes > 0
     algo_bytes_launch = n_local * ((d + 127) // 128 * 128) if int8_batch else n_local * d * (2 if dom == "filter" else elem)
     achieved = (algo_bytes_launch / avg_launch_s / 1e9) if avg_launch_s else None
     line = {
@@ -327,6 +327,15 @@ def main():
             "launches_timed": kernels[dom]["launches"] if dom else 0,
             "events_from": "the timed region" if depth == 1 else "the same K steps repeated on one stream after the timed region",
             "all_kernels": kernels,
+            # SURVEY.md §8(d) prices a pass at the STORED corpus bytes (N*d*bytes_per_elem); the filter streams a
+            # narrower derived copy instead, so against that figure the launch runs above the HBM roof
+            "stored_corpus_equivalent_GBps": (n_local * d * elem / avg_launch_s / 1e9) if avg_launch_s else None,
+            # the other side of the ridge for the same launch: multiply-accumulates of the filter GEMM (2*B*rows*d per
+            # launch) against the dense matrix peak of its operand type (MI355X_MICROARCH.md: bf16 2.5 PFLOP/s, i8 2x that)
+            "matrix_side": ({"achieved": 2.0 * B * n_local * d / avg_launch_s / 1e12, "peak": 5000.0 if int8_batch else 2500.0,
+                             "unit": "TOP/s" if int8_batch else "TFLOP/s",
+                             "frac": 2.0 * B * n_local * d / avg_launch_s / 1e12 / (5000.0 if int8_batch else 2500.0)}
+                            if dom == "filter" and avg_launch_s else None),
         },
         "filter_stats": filter_stats,
     }

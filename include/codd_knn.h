@@ -172,7 +172,7 @@ int codd_knn_ivf_search(codd_knn_index* index, const float* dev_queries, int B, 
  *            fewer than one tile per CU once the corpus has two rounds of tiles), "sample_tiles"
  *            (4096: upper bound on that number), "hit_cap" (per-query
  *            candidate capacity; overflow falls back to the exact scan);
- *            "shadow8" (1: batches of <= "shadow8_max_batch" (8) queries are filtered through an
+ *            "shadow8" (1: batches of <= "shadow8_max_batch" (256) queries are filtered through an
  *            int8 copy of the corpus, 1 byte per element, derived lazily from the stored rows and
  *            kept up to date incrementally; results stay exact; an index whose worst row quantises
  *            badly — error norm above 0.04 — keeps the bf16 filter), "sample_div8" (20);

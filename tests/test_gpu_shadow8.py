@@ -1,4 +1,4 @@
-"""The optional int8 shadow for small batches ("shadow8"): half the bytes of the bf16 shadow per pass.  The filter is
+"""The int8 shadow ("shadow8", on by default for batches of <= 256 queries): half the bytes of the bf16 shadow per pass.  The filter is
 still only a filter: survivors are re-scored with the canonical fp32 expression, so ids and distances must equal the
 oracle's bit for bit; what changes is the error bound (per query, from the exact quantisation error norms)."""
 
@@ -26,7 +26,7 @@ def build8(Index, raw, dtype="f32"):
     for key in ("filter_min_rows", "filter_min_rows_small", "filter_min_batch"):
         ix.set_option(key, 1)
     ix.set_option("shadow8", 1)
-    ix.set_option("shadow8_max_batch", 32)  # (default 8: beyond that the int8 filter's candidate volume outweighs the bytes it saves)
+    ix.set_option("shadow8_max_batch", 32)
     return ix
 
 
