@@ -293,8 +293,12 @@ def test_full_baseline_size_properties(Index):
     assert rows[:3].cpu().numpy().tolist() == np.array(planted).reshape(3, k).tolist()
     assert bool((dist[:, 1:] >= dist[:, :-1]).all()) and bool((rows >= 0).all())
     assert ix.stat("filter_passes") == 1 and ix.stat("fallback_queries") == 0
+    assert ix.stat("shadow8_passes") == 1                      # the default for a batch of <= 256 queries: the int8 filter
     d1, r1 = ix.search_tensors(q[7:8], k)                      # single-query path (NBQ = 1 instantiation)
     assert torch.equal(r1[0], rows[7]) and torch.equal(d1[0], dist[7])
+    ix.set_option("shadow8", 0)                                # the bf16 filter must return the same bits
+    d2, r2 = ix.search_tensors(q, k)
+    assert ix.stat("shadow8_passes") == 2 and torch.equal(r2, rows) and torch.equal(d2, dist)
     ix.set_option("filter", 0)
     de, re_ = ix.search_tensors(q[:8], k)                      # exact scan, one pass over 30.7 GB
     assert torch.equal(re_, rows[:8]) and torch.equal(de, dist[:8])

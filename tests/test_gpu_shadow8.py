@@ -84,6 +84,12 @@ def test_int8_scores_match_integer_reference(Index, n, d, B, dtype):
         (12_000, 1024, 3, 10, "f16"),
         (30_000, 64, 9, 10, "f32"),      # one 64-wide row padded to one 128-element K-step
         (30_000, 320, 31, 10, "f32"),    # 3 int8 K-steps (dpad8 = 384)
+        (70_000, 768, 256, 10, "f32"),   # the headline shape, scaled down (NBQ = 8)
+        (50_000, 768, 100, 10, "f32"),   # NBQ = 4
+        (33_000, 384, 64, 10, "f32"),    # NBQ = 2
+        (70_000, 256, 129, 100, "f32"),  # k = 100 (two list slots), ragged batch
+        (40_000, 768, 96, 10, "bf16"),
+        (20_000, 2048, 40, 10, "bf16"),  # widest row
     ],
 )
 def test_int8_filter_path_is_exact(Index, n, d, B, k, dtype):
@@ -91,6 +97,7 @@ def test_int8_filter_path_is_exact(Index, n, d, B, k, dtype):
     raw = rng.standard_normal((n, d)).astype(np.float32)
     q = rng.standard_normal((B, d)).astype(np.float32)
     ix = build8(Index, raw, dtype)
+    ix.set_option("shadow8_max_batch", 256)
     dist, rows = ix.search(q, k)
     assert ix.stat("shadow8_passes") == 1 and ix.stat("shadow8_builds") == 1
     rows_ref = o.to_storage(o.normalize_rows(raw), dtype)
