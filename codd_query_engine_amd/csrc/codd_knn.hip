@@ -1323,18 +1323,22 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
         if (hipEventQuery(ix->eps_r_copied) == hipSuccess) ix->eps_r_known = *ix->eps_r_host;
         else (void)hipGetLastError();  // "not ready" must not surface in a later error check
     }
-    const bool use8 = fused_prep && ix->shadow8_enabled && B <= ix->shadow8_max_batch && CODD_MFMA16 &&
-                      ix->eps_r_known <= ix->shadow8_max_eps;
+    // the int8 filter: every pass of <= 256 queries prepares its own block (a batch above 256 queries is several passes)
+    const bool use8 = use_filter && ix->shadow8_enabled && (B <= ix->shadow8_max_batch || (B > kTileQ && ix->shadow8_max_batch >= kTileQ)) &&
+                      CODD_MFMA16 && ix->eps_r_known <= ix->shadow8_max_eps;
+    const int dpad8 = dpad8_of(ix);
+    auto prep8 = [&](int q0, int nq) -> int {
+        hipLaunchKernelGGL(prep_queries8_kernel, dim3(kTileQ / 4), dim3(256), 0, st, dev_queries + (int64_t)q0 * ix->dim, nq, ix->dim, ix->dpad, dpad8,
+                           ix->qn + (int64_t)q0 * ix->dpad, reinterpret_cast<uint32_t*>(ix->qfrag8), ix->qmeta, ix->eps_r_bits,
+                           reinterpret_cast<unsigned*>(ix->ctl), (int)(sizeof(FilterCtl) / 4), ix->exp_slack_scale);
+        HIP_TRY(hipGetLastError());
+        return CODD_KNN_OK;
+    };
     if (use8) {
         if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
         if ((rc = ensure_shadow8(ix, st)) != 0) return rc;
-        const int dpad8 = dpad8_of(ix);
         if ((rc = ensure_buf(&ix->qfrag8, &ix->qfrag8_cap, (int64_t)kTileQ * (dpad8 / 16))) != 0) return rc;
         if (!ix->qmeta) HIP_TRY(hipMalloc((void**)&ix->qmeta, 512 * sizeof(float)));
-        hipLaunchKernelGGL(prep_queries8_kernel, dim3(kTileQ / 4), dim3(256), 0, st, dev_queries, B, ix->dim, ix->dpad, dpad8, ix->qn,
-                           reinterpret_cast<uint32_t*>(ix->qfrag8), ix->qmeta, ix->eps_r_bits, reinterpret_cast<unsigned*>(ix->ctl),
-                           (int)(sizeof(FilterCtl) / 4), ix->exp_slack_scale);
-        HIP_TRY(hipGetLastError());
     } else if (fused_prep) {
         if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
         hipLaunchKernelGGL(prep_queries_kernel, dim3(kTileQ / 4), dim3(256), 0, st, dev_queries, B, ix->dim, ix->dpad, ix->qn,
@@ -1355,7 +1359,8 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
         if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
         for (int q0 = 0; q0 < B; q0 += kTileQ) {
             const int nq = B - q0 < kTileQ ? B - q0 : kTileQ;
-            if ((rc = filter_pass(ix, ix->qn + (int64_t)q0 * ix->dpad, nq, k, row_base, keys_dst + (int64_t)q0 * k, st, fused_prep, use8)) != 0)
+            if (use8 && (rc = prep8(q0, nq)) != 0) return rc;
+            if ((rc = filter_pass(ix, ix->qn + (int64_t)q0 * ix->dpad, nq, k, row_base, keys_dst + (int64_t)q0 * k, st, fused_prep || use8, use8)) != 0)
                 return rc;
         }
     } else {
