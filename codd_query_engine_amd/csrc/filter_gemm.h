@@ -870,15 +870,23 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
         __syncthreads();
         const unsigned ns = lds_n;
         survivors += ns;
-        for (unsigned j = wave * 4; j < ns; j += 16) {
-            unsigned rowid[4];
-            float sc4[4];
+        // eight rows per wave step: two independent groups of four, so that both groups' row reads are in flight
+        // before the first is consumed (the loop is a chain of HBM round trips otherwise)
+        for (unsigned j0 = wave * 8; j0 < ns; j0 += 32) {
+            unsigned rowid8[2][4];
+            float sc8[2][4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) rowid[r] = lds_surv[j + r < ns ? j + r : ns - 1];
-            rescore4(rowid, sc4);
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float sc = sc4[r];
+                for (int r = 0; r < 4; ++r) rowid8[h][r] = lds_surv[j0 + 4 * h + r < ns ? j0 + 4 * h + r : ns - 1];
+            rescore4(rowid8[0], sc8[0]);
+            rescore4(rowid8[1], sc8[1]);
+#pragma unroll
+            for (int hr = 0; hr < 8; ++hr) {
+                const int r = hr & 3;
+                const unsigned j = j0 + 4 * (hr >> 2);
+                const unsigned (&rowid)[4] = rowid8[hr >> 2];
+                const float sc = sc8[hr >> 2][r];
                 if (j + r < ns) X.offer(make_key(sc, row_base + rowid[r]), k, lane);
             }
         }
@@ -946,8 +954,8 @@ __global__ __launch_bounds__(64) void anchor_thr_kernel(const u64* __restrict__ 
         return;
     }
     const uint4* base = reinterpret_cast<const uint4*>(rows_);
-    float worst = INFINITY;
-    for (int j = 0; j < k; j += 4) {
+    // exact scores of the rows ranked [j, j+4) (ranks past k-1 repeat the last one)
+    auto group = [&](int j, float (&sc)[4]) __attribute__((always_inline)) {
         float w[4][NITER][E];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -973,9 +981,17 @@ __global__ __launch_bounds__(64) void anchor_thr_kernel(const u64* __restrict__ 
         }
         const float y = butterfly_sum4(a[0], a[1], a[2], a[3], lane);
 #pragma unroll
+        for (int r = 0; r < 4; ++r) sc[r] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(y), 16 * r));
+    };
+    float worst = INFINITY;
+    for (int j = 0; j < k; j += 8) {  // two independent groups per step: both groups' row reads fly together
+        float s0[4], s1[4];
+        group(j, s0);
+        group(j + 4, s1);
+#pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(y), 16 * r));
-            if (j + r < k) worst = fminf(worst, sc);
+            if (j + r < k) worst = fminf(worst, s0[r]);
+            if (j + 4 + r < k) worst = fminf(worst, s1[r]);
         }
     }
     if (lane == 0) thr[q] = worst - (two_eps_q ? 0.5f * two_eps_q[q] : eps);
