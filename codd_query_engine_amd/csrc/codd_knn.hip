@@ -672,6 +672,22 @@ struct codd_knn_index : WorkBufs {
     hipEvent_t eps_r_copied = nullptr;
     float eps_r_known = 0.0f;
     float shadow8_max_eps = 0.04f;
+    // Which filter suits the DATA is watched too: on corpora with dense clusters the wider int8 slack lets thousands of
+    // rows per query through to the exact re-scoring, where the bf16 filter (a fifth of the slack) is the faster one
+    // (profiles/r1/clustered_data_check.txt).  The device counters of the filter passes are copied back
+    // asynchronously; when the int8 passes since the last look left more than shadow8_max_surv survivors per query, or
+    // sent queries to the fallback, the next shadow8_cooldown searches take the bf16 filter, then the int8 one is
+    // tried again.  Performance only: either filter returns the same bits.
+    unsigned long long* watch_host = nullptr;  // pinned copy of dstats[0..3]
+    hipEvent_t watch_copied = nullptr;
+    bool watch_pending = false;
+    unsigned long long watch_surv = 0, watch_fb = 0;  // counter values at the last look
+    int64_t watch_q8 = 0, watch_q16 = 0;              // queries filtered since then, by path
+    int64_t watch_q8_sent = 0, watch_q16_sent = 0;    // ... as of the copy in flight
+    int shadow8_max_surv = 4000;
+    int shadow8_cooldown = 256;
+    int cooldown_left = 0;
+    int64_t stat_cooldowns = 0;
     float exp_slack_scale = 1.0f;  // diagnostic only ("exp_slack_pct"): < 1 makes the int8 filter UNSOUND; what-if timing
 
     // IVF (optional): rows regrouped by coarse list, original slots, list offsets, the coarse index
@@ -1323,8 +1339,29 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
         if (hipEventQuery(ix->eps_r_copied) == hipSuccess) ix->eps_r_known = *ix->eps_r_host;
         else (void)hipGetLastError();  // "not ready" must not surface in a later error check
     }
+    if (ix->watch_pending && ix->watch_copied) {
+        if (hipEventQuery(ix->watch_copied) == hipSuccess) {
+            ix->watch_pending = false;
+            const unsigned long long surv = ix->watch_host[1], fb = ix->watch_host[2];
+            if (ix->watch_q8_sent > 0 && ix->watch_q16_sent == 0) {  // only int8 passes in the window: the deltas are theirs
+                const double per_q = (double)(surv - ix->watch_surv) / (double)ix->watch_q8_sent;
+                if (per_q > (double)ix->shadow8_max_surv || (fb - ix->watch_fb) * 20 > (unsigned long long)ix->watch_q8_sent) {
+                    ix->cooldown_left = ix->shadow8_cooldown;
+                    ix->stat_cooldowns++;
+                }
+            }
+            ix->watch_surv = surv;
+            ix->watch_fb = fb;
+            ix->watch_q8 -= ix->watch_q8_sent;
+            ix->watch_q16 -= ix->watch_q16_sent;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    const bool cooling = ix->cooldown_left > 0;
+    if (cooling && use_filter) ix->cooldown_left--;
     // the int8 filter: every pass of <= 256 queries prepares its own block (a batch above 256 queries is several passes)
-    const bool use8 = use_filter && ix->shadow8_enabled && (B <= ix->shadow8_max_batch || (B > kTileQ && ix->shadow8_max_batch >= kTileQ)) &&
+    const bool use8 = use_filter && !cooling && ix->shadow8_enabled && (B <= ix->shadow8_max_batch || (B > kTileQ && ix->shadow8_max_batch >= kTileQ)) &&
                       CODD_MFMA16 && ix->eps_r_known <= ix->shadow8_max_eps;
     const int dpad8 = dpad8_of(ix);
     auto prep8 = [&](int q0, int nq) -> int {
@@ -1362,6 +1399,18 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
             if (use8 && (rc = prep8(q0, nq)) != 0) return rc;
             if ((rc = filter_pass(ix, ix->qn + (int64_t)q0 * ix->dpad, nq, k, row_base, keys_dst + (int64_t)q0 * k, st, fused_prep || use8, use8)) != 0)
                 return rc;
+        }
+        (use8 ? ix->watch_q8 : ix->watch_q16) += B;
+        if (ix->shadow8_enabled && !ix->watch_pending && ix->dstats) {  // one look in flight at a time
+            if (!ix->watch_host) {
+                HIP_TRY(hipHostMalloc((void**)&ix->watch_host, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+                HIP_TRY(hipEventCreateWithFlags(&ix->watch_copied, hipEventDisableTiming));
+            }
+            HIP_TRY(hipMemcpyAsync(ix->watch_host, ix->dstats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipEventRecord(ix->watch_copied, st));
+            ix->watch_pending = true;
+            ix->watch_q8_sent = ix->watch_q8;
+            ix->watch_q16_sent = ix->watch_q16;
         }
     } else {
         // small batches: the per-block partials merge straight into the caller's buffers
@@ -1422,6 +1471,8 @@ int codd_knn_destroy(codd_knn_index* ix) {
     (void)hipDeviceSynchronize();
     void* bufs[] = {ix->rows, ix->shadow, ix->dstats, ix->rows_ivf, ix->ivf_ids, ix->ivf_offsets, ix->shadow8, ix->rscale, ix->eps_r_bits};
     if (ix->shadow8_ready) (void)hipEventDestroy(ix->shadow8_ready);
+    if (ix->watch_copied) (void)hipEventDestroy(ix->watch_copied);
+    if (ix->watch_host) (void)hipHostFree(ix->watch_host);
     if (ix->eps_r_copied) (void)hipEventDestroy(ix->eps_r_copied);
     if (ix->eps_r_host) (void)hipHostFree(ix->eps_r_host);
     for (void* b : bufs)
@@ -1747,6 +1798,17 @@ int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {
         ix->shadow8_max_batch = (int)value;
         return CODD_KNN_OK;
     }
+    if (strcmp(key, "shadow8_max_surv") == 0) {
+        if (value < 1 || value > 1000000) return fail(CODD_KNN_EINVAL, "shadow8_max_surv must be in [1,1000000]%s");
+        ix->shadow8_max_surv = (int)value;
+        return CODD_KNN_OK;
+    }
+    if (strcmp(key, "shadow8_cooldown") == 0) {
+        if (value < 0 || value > 1000000) return fail(CODD_KNN_EINVAL, "shadow8_cooldown must be in [0,1000000]%s");
+        ix->shadow8_cooldown = (int)value;
+        ix->cooldown_left = 0;
+        return CODD_KNN_OK;
+    }
     if (strcmp(key, "exp_slack_pct") == 0) {  // diagnostic: see exp_slack_scale
         if (value < 1 || value > 100) return fail(CODD_KNN_EINVAL, "exp_slack_pct must be in [1,100]%s");
         ix->exp_slack_scale = (float)value / 100.0f;
@@ -1821,6 +1883,7 @@ int codd_knn_get_stat(const codd_knn_index* ix, const char* key, int64_t* out) {
     else if (strcmp(key, "filter_passes") == 0) *out = ix->stat_filter_passes;
     else if (strcmp(key, "shadow8_builds") == 0) *out = ix->stat_shadow8_builds;
     else if (strcmp(key, "shadow8_passes") == 0) *out = ix->stat_shadow8_passes;
+    else if (strcmp(key, "shadow8_cooldowns") == 0) *out = ix->stat_cooldowns;
     else if (strcmp(key, "shadow8_eps_r_micro") == 0) {  // worst row's quantisation error norm x 1e6, as last read back
         if (ix->eps_r_copied && hipEventQuery(ix->eps_r_copied) == hipSuccess) *out = (int64_t)(*ix->eps_r_host * 1e6f);
         else {

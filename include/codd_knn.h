@@ -175,12 +175,15 @@ int codd_knn_ivf_search(codd_knn_index* index, const float* dev_queries, int B, 
  *            "shadow8" (1: batches of <= "shadow8_max_batch" (256) queries are filtered through an
  *            int8 copy of the corpus, 1 byte per element, derived lazily from the stored rows and
  *            kept up to date incrementally; results stay exact; an index whose worst row quantises
- *            badly — error norm above 0.04 — keeps the bf16 filter), "sample_div8" (20);
+ *            badly — error norm above 0.04 — keeps the bf16 filter; so does, for the next
+ *            "shadow8_cooldown" (256) searches, an index whose int8 passes leave more than
+ *            "shadow8_max_surv" (4000) survivors per query or send queries to the fallback: dense
+ *            clusters), "sample_div8" (20);
  *            "profile" = N keeps N (start, stop) HIP-event pairs, one per heavy-kernel launch,
  *            recorded on the launch stream (0 = off; resets the log)
  *   stats  : "searches", "scan_launches", "last_scan_blocks", "filter_passes",
  *            "fallback_queries", "filter_hits", "filter_survivors", "capacity_rows",
- *            "device_bytes", "num_cus", "workspaces" (stream workspaces in use), "shadow8_builds", "shadow8_passes", "shadow8_eps_r_micro", and per kernel K in {scan, filter, sample, finalize}:
+ *            "device_bytes", "num_cus", "workspaces" (stream workspaces in use), "shadow8_builds", "shadow8_passes", "shadow8_cooldowns", "shadow8_eps_r_micro", and per kernel K in {scan, filter, sample, finalize}:
  *            "events:K", "time_ns:K" (sum of the recorded launches; syncs on the last event)
  */
 int codd_knn_set_option(codd_knn_index* index, const char* key, int64_t value);

@@ -19,6 +19,7 @@ for centres, noise in ((4096, 0.5), (4096, 0.2), (256, 0.3), (64, 0.1)):
         ix.upsert_device(c0, (c[which] + noise * torch.randn((m, d), generator=g, device="cuda") / d ** 0.5).contiguous())
     which = torch.randint(0, centres, (B,), generator=g, device="cuda")
     q = c[which] + noise * torch.randn((B, d), generator=g, device="cuda") / d ** 0.5
+    ix.set_option("shadow8", int(os.environ.get("CODD_SHADOW8", "1")))
     for _ in range(2):
         ix.search_tensors(q, k)
     torch.cuda.synchronize()

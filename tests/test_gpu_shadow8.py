@@ -179,3 +179,32 @@ def test_badly_quantisable_rows_turn_the_int8_filter_off_not_wrong(Index):
     assert ix.stat("shadow8_passes") == passes8, "the index should have gone back to the bf16 filter"
     assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
     ix.close()
+
+
+def test_dense_clusters_send_the_index_back_to_the_bf16_filter(Index):
+    """Clustered corpora (what embedding corpora look like): the int8 slack lets whole clusters through to the exact
+    re-scoring.  The index watches its own counters and takes the bf16 filter for a while; results are the same bits
+    either way."""
+    import torch
+
+    n, d, B, k = 200_000, 256, 64, 10
+    g = torch.Generator(device="cuda").manual_seed(3)
+    c = torch.nn.functional.normalize(torch.randn((16, d), generator=g, device="cuda"), dim=1)
+    x = c[torch.randint(0, 16, (n,), generator=g, device="cuda")] + 0.3 * torch.randn((n, d), generator=g, device="cuda") / d ** 0.5
+    q = c[torch.randint(0, 16, (B,), generator=g, device="cuda")] + 0.3 * torch.randn((B, d), generator=g, device="cuda") / d ** 0.5
+    ix = Index(d)
+    ix.upsert_device(0, x.contiguous())
+    outs = []
+    for _ in range(4):
+        outs.append(ix.search_tensors(q, k))
+        torch.cuda.synchronize()
+    assert ix.stat("shadow8_passes") >= 1 and ix.stat("shadow8_cooldowns") >= 1
+    passes8 = ix.stat("shadow8_passes")
+    outs.append(ix.search_tensors(q, k))
+    torch.cuda.synchronize()
+    assert ix.stat("shadow8_passes") == passes8, "cooling down: this search must have taken the bf16 filter"
+    ix.set_option("filter", 0)
+    d_ref, r_ref = ix.search_tensors(q, k)
+    for dd, rr in outs:
+        assert torch.equal(rr, r_ref) and torch.equal(dd, d_ref)
+    ix.close()
