@@ -17,10 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 VARIANTS = {
-    "nohits": {"CODD_EXP_NO_HITS": 1},
-    "nohits_sametile": {"CODD_EXP_NO_HITS": 1, "CODD_EXP_SAME_TILE": 1},
-    "nohits_nb1": {"CODD_EXP_NO_HITS": 1, "CODD_EXP_NB": 1},
-    "nohits_noqstage": {"CODD_EXP_NO_HITS": 1, "CODD_EXP_NO_QSTAGE": 1},
+    "base": {},
+    "old": {},
 }
 
 
