@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "base": {},
-    "old": {},
+    # add {"name": {"CODD_...": value}} entries here; CODD_EXP_INT8=1 in the environment also times the int8 filter
 }
 
 
