@@ -208,3 +208,32 @@ def test_dense_clusters_send_the_index_back_to_the_bf16_filter(Index):
     for dd, rr in outs:
         assert torch.equal(rr, r_ref) and torch.equal(dd, d_ref)
     ix.close()
+
+
+def test_rebuild_on_one_stream_is_awaited_by_searches_on_others(Index):
+    """After rows changed, the first search rebuilds the int8 shadow on ITS stream; a search issued right behind it on
+    another stream must wait for that build on the device, not read a half-written shadow."""
+    import torch
+
+    rng = np.random.default_rng(9)
+    raw = rng.standard_normal((150_000, 256)).astype(np.float32)
+    ix = build8(Index, raw)
+    qs = [torch.from_numpy(rng.standard_normal((b, 256)).astype(np.float32)).cuda() for b in (4, 30)]
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for round_ in range(3):
+        new = rng.standard_normal((20_000, 256)).astype(np.float32)
+        first = 150_000 + 20_000 * round_
+        ix.upsert(np.arange(first, first + 20_000, dtype=np.int64), new)     # rows changed: the shadow is stale
+        raw = np.concatenate([raw, new])
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            o1 = ix.search_tensors(qs[0], 10)                                  # rebuilds on s1
+        with torch.cuda.stream(s2):
+            o2 = ix.search_tensors(qs[1], 10)                                  # must wait for it on s2
+        torch.cuda.synchronize()
+        rows_ref = o.normalize_rows(raw)
+        for q, (dd, rr) in zip(qs, (o1, o2)):
+            d_ref, i_ref = o.search(rows_ref, "f32", o.normalize_rows(q.cpu().numpy()), 10)
+            assert np.array_equal(rr.cpu().numpy(), i_ref) and np.array_equal(dd.cpu().numpy(), d_ref)
+    assert ix.stat("shadow8_builds") == 3  # one per round: the first one builds everything, the others only the appended rows
+    ix.close()
