@@ -1097,6 +1097,8 @@ int64_t sample_tile_count(const codd_knn_index* ix, int64_t ntiles, int k, bool 
     // a sample of fewer tiles than there are CUs takes as long as one full round of workgroups (one tile each), and a
     // bigger sample means a tighter threshold: fewer hits for the filter's epilogue (scripts/rows_sweep.py)
     if (ts < ix->num_cus && ntiles >= 2 * (int64_t)ix->num_cus) ts = ix->num_cus;
+    // whole rounds of workgroups: the last round costs a round whether it is full or not
+    if (ts > ix->num_cus) ts = (ts + ix->num_cus - 1) / ix->num_cus * ix->num_cus;
     if (ts > ix->sample_tiles) ts = ix->sample_tiles;
     if (ts > ntiles) ts = ntiles;
     return ts < 1 ? 1 : ts;
