@@ -655,6 +655,7 @@ struct codd_knn_index : WorkBufs {
     // int8 shadow for small batches (optional; rebuilt lazily from the stored rows when they have changed)
     int shadow8_enabled = 1;
     int shadow8_max_batch = 256;  // batches up to this size (one query pass) take the int8 filter
+    int resident_q = 1;           // rows of <= 512 int8 elements: the query block stays in LDS ("resident_q" option)
     int sample_div8 = 20;         // its thresholds come from a larger sample (the int8 slack is ~5x the bf16 one)
     uint4* shadow8 = nullptr;
     int64_t shadow8_rows = 0;     // rows the allocation covers (multiple of 256)
@@ -1173,6 +1174,7 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     const uint4* qfrag = use8 ? ix->qfrag8 : ix->qfrag;
     const float* slack_q = use8 ? ix->qmeta + 256 : nullptr;  // int8: 2*eps per query, written by prep_queries8_kernel
     if (use8) ix->stat_shadow8_passes++;
+    const bool resident = use8 && nsteps <= 4 && ix->resident_q;
     const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
     const int slots = k <= 64 ? 1 : 2;
     const float eps = filter_eps(ix);
@@ -1199,7 +1201,17 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
 #define CODD_LAUNCH_SAMPLE8(NBQ)                                                                                             \
     hipLaunchKernelGGL((gemm_filter_kernel<MODE_SAMPLE, NBQ, 1>), g, b, lds, st, shadow, qfrag, n, nsteps, ts, stride, \
                        nullptr, ix->bucket_max, nullptr, nullptr, 0, nullptr, nullptr, ix->rscale, ix->qmeta)
-        if (use8) {
+#define CODD_LAUNCH_SAMPLE8R(NBQ)                                                                                            \
+    hipLaunchKernelGGL((gemm_filter_kernel<MODE_SAMPLE, NBQ, 1, 1>), g, b, lds, st, shadow, qfrag, n, nsteps, ts, stride, \
+                       nullptr, ix->bucket_max, nullptr, nullptr, 0, nullptr, nullptr, ix->rscale, ix->qmeta)
+        if (use8 && resident) {  // the whole int8 query block fits the LDS slices: loaded once per workgroup
+            switch (nbq) {
+                case 1: CODD_LAUNCH_SAMPLE8R(1); break;
+                case 2: CODD_LAUNCH_SAMPLE8R(2); break;
+                case 4: CODD_LAUNCH_SAMPLE8R(4); break;
+                default: CODD_LAUNCH_SAMPLE8R(8); break;
+            }
+        } else if (use8) {
             switch (nbq) {
                 case 1: CODD_LAUNCH_SAMPLE8(1); break;
                 case 2: CODD_LAUNCH_SAMPLE8(2); break;
@@ -1215,6 +1227,7 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
         }
 #undef CODD_LAUNCH_SAMPLE
 #undef CODD_LAUNCH_SAMPLE8
+#undef CODD_LAUNCH_SAMPLE8R
     }
     HIP_TRY(hipGetLastError());
     {
@@ -1248,7 +1261,17 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
 #define CODD_LAUNCH_FILTER8(NBQ)                                                                                            \
     hipLaunchKernelGGL((gemm_filter_kernel<MODE_FILTER, NBQ, 1>), g, b, lds, st, shadow, qfrag, n, nsteps, ntiles,  \
                        (int64_t)1, ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, nullptr, ix->rscale, ix->qmeta)
-        if (use8) {
+#define CODD_LAUNCH_FILTER8R(NBQ)                                                                                           \
+    hipLaunchKernelGGL((gemm_filter_kernel<MODE_FILTER, NBQ, 1, 1>), g, b, lds, st, shadow, qfrag, n, nsteps, ntiles, \
+                       (int64_t)1, ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, nullptr, ix->rscale, ix->qmeta)
+        if (use8 && resident) {
+            switch (nbq) {
+                case 1: CODD_LAUNCH_FILTER8R(1); break;
+                case 2: CODD_LAUNCH_FILTER8R(2); break;
+                case 4: CODD_LAUNCH_FILTER8R(4); break;
+                default: CODD_LAUNCH_FILTER8R(8); break;
+            }
+        } else if (use8) {
             switch (nbq) {
                 case 1: CODD_LAUNCH_FILTER8(1); break;
                 case 2: CODD_LAUNCH_FILTER8(2); break;
@@ -1264,6 +1287,7 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
         }
 #undef CODD_LAUNCH_FILTER
 #undef CODD_LAUNCH_FILTER8
+#undef CODD_LAUNCH_FILTER8R
     }
     HIP_TRY(hipGetLastError());
     const int nchunks = ix->dpad / elems_per_chunk(ix->dtype);
@@ -1814,6 +1838,11 @@ int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {
     if (strcmp(key, "exp_slack_pct") == 0) {  // diagnostic: see exp_slack_scale
         if (value < 1 || value > 100) return fail(CODD_KNN_EINVAL, "exp_slack_pct must be in [1,100]%s");
         ix->exp_slack_scale = (float)value / 100.0f;
+        return CODD_KNN_OK;
+    }
+    if (strcmp(key, "resident_q") == 0) {
+        if (value != 0 && value != 1) return fail(CODD_KNN_EINVAL, "resident_q must be 0 or 1%s");
+        ix->resident_q = (int)value;
         return CODD_KNN_OK;
     }
     if (strcmp(key, "sample_div8") == 0) {

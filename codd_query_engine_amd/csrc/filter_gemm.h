@@ -284,7 +284,10 @@ __device__ __forceinline__ void flush_hits_binned(const unsigned* lds_hits, unsi
 // EL = 1: the operands are int8 with one fp32 scale per corpus row (rscale) and per query (qscale): 128 elements per
 // K-step instead of 64, v_mfma_i32_16x16x64_i8 (twice the bf16 rate, half the bytes), exact integer accumulation; a
 // score is acc * rscale[row] * qscale[query].  The piece / ring / LDS geometry is byte-identical to the bf16 mode.
-template <int MODE, int NBQ, int EL = 0>
+// RES = 1 (only launched when the row has at most 4 K-steps, i.e. the whole query block fits the 4 LDS slices): the
+// query block is loaded into LDS once per workgroup and never re-staged — no staging loads, LDS writes or stage barriers
+// in the loop (re-staging costs 15-19 % of the kernel, profiles/r1/v5_hit_flush_ablation.txt).
+template <int MODE, int NBQ, int EL = 0, int RES = 0>
 __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gemm_filter_kernel(
     const uint4* __restrict__ shadow, const uint4* __restrict__ qfrag, int64_t n, int nsteps, int64_t ntiles_run,
     int64_t tile_stride, const float* __restrict__ thr, u64* __restrict__ bucket_key, u64* __restrict__ hits,
@@ -381,7 +384,8 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
     const int stid = kSP >= kFilterThreads ? tid : tid % kSP;
     typedef unsigned q4u __attribute__((ext_vector_type(4)));  // (native vectors: uint4 staging buffers end up as scratch allocas)
 #pragma unroll
-    for (int sub = 0; sub < kQS; ++sub) {
+    for (int sub = 0; sub < (RES ? 2 * kQS : kQS); ++sub) {
+        if (RES && sub >= nsteps) break;  // resident: slice s lives in LDS slice s for the whole kernel
         const uint4* src = qfrag + (int64_t)q_s * kStagePieces + stid;
         uint4* dst = ldsQ + sub * kStagePieces + stid;
         q4u tmp[kQPn];
@@ -415,7 +419,8 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
     // their loads, waits and epilogues at different times instead of in lockstep (MI355X_MICROARCH.md, "two waves per
     // SIMD", item 9).  Slice hazards with 4 LDS slices: interval t reads slices t-1 and t and writes slice t+2.
     // ------------------------------------------------------------------------------------------------------------
-    constexpr int kLag = (CODD_STAGGER && MODE == MODE_FILTER && kKS == 2) ? 1 : 0;
+    constexpr int kLag = (CODD_STAGGER && MODE == MODE_FILTER && kKS == 2 && !RES) ? 1 : 0;
+    constexpr bool kNoStage = CODD_EXP_NO_QSTAGE || RES;
     constexpr bool kBarrierEveryStep = kLag == 1;
     constexpr int kNqbRun = (CODD_EXP_NB < NBQ ? CODD_EXP_NB : NBQ) * kQBper32 / kQSplit;
     const int TI = T + kLag;  // intervals
@@ -585,7 +590,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                 // query slice of step t+kQS: issue now, write to LDS at the end of the interval
                 {
                     const uint4* src = qfrag + (int64_t)q_s * kStagePieces + stid;
-                    if (!CODD_EXP_NO_QSTAGE) {
+                    if (!kNoStage) {
 #pragma unroll
                         for (int j = 0; j < kQPn; ++j) (iu % kQD ? qreg1 : qreg0)[j] = reinterpret_cast<const q4u*>(src)[j * kFilterThreads];
                     }
@@ -599,7 +604,8 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
 #if CODD_MFMA_PRIO
                     __builtin_amdgcn_s_setprio(1);
 #endif
-                    mfma_part(std::integral_constant<int, i>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, kKS>{}, slice_ptr(t));
+                    mfma_part(std::integral_constant<int, i>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, kKS>{},
+                              RES ? ldsQ + c_s * kStagePieces + lane + qoff : slice_ptr(t));
 #if CODD_MFMA_PRIO
                     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -607,7 +613,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                     // pin the step's shape: all 8 global loads (4 query, 4 corpus) first so they fly under the
                     // MFMAs; at most a few query fragments live (4 LDS reads up front, then one per MFMA);
                     // the LDS writes of the next query slice last
-                    __builtin_amdgcn_sched_group_barrier(0x020, 4 * kRB + (CODD_EXP_NO_QSTAGE ? 0 : kQPn), 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 4 * kRB + (kNoStage ? 0 : kQPn), 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
                     for (int g = 0; g < kKS * kNqbRun - 4; ++g) {
@@ -615,11 +621,11 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
                     __builtin_amdgcn_sched_group_barrier(0x008, 4 * kRS, 0);
-                    if (!CODD_EXP_NO_QSTAGE) __builtin_amdgcn_sched_group_barrier(0x200, kQPn, 0);
+                    if (!kNoStage) __builtin_amdgcn_sched_group_barrier(0x200, kQPn, 0);
 #endif
                     {
                         uint4* dstq = ldsQ + (((stage + 1) & 1) * kQS + sub) * kStagePieces + stid;
-                        if (!CODD_EXP_NO_QSTAGE) {
+                        if (!kNoStage) {
 #pragma unroll
                             for (int j = 0; j < kQPn; ++j)
                                 reinterpret_cast<q4u*>(dstq)[j * kFilterThreads] = ((iu + kQD - 1) % kQD ? qreg1 : qreg0)[j];
@@ -633,7 +639,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                     mfma_part(std::integral_constant<int, (i + kRing - 1) % kRing>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{},
                               slice_ptr(t - 1));
 #if CODD_PIN_SCHEDULE && !CODD_EXP_NO_LDSREAD
-                    __builtin_amdgcn_sched_group_barrier(0x020, (CODD_EXP_NO_QSTAGE ? 0 : kQPn), 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, (kNoStage ? 0 : kQPn), 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
                     for (int g = 0; g < kNqbRun - 4; ++g) {
@@ -665,11 +671,11 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
                     __builtin_amdgcn_sched_group_barrier(0x008, 4 * kRS, 0);
-                    if (!CODD_EXP_NO_QSTAGE) __builtin_amdgcn_sched_group_barrier(0x200, kQPn, 0);
+                    if (!kNoStage) __builtin_amdgcn_sched_group_barrier(0x200, kQPn, 0);
 #endif
                     {
                         uint4* dstq = ldsQ + (((stage + 1) & 1) * kQS + sub) * kStagePieces + stid;
-                        if (!CODD_EXP_NO_QSTAGE) {
+                        if (!kNoStage) {
 #pragma unroll
                             for (int j = 0; j < kQPn; ++j)
                                 reinterpret_cast<q4u*>(dstq)[j * kFilterThreads] = ((iu + kQD - 1) % kQD ? qreg1 : qreg0)[j];
@@ -682,7 +688,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                 const bool wg_tile_end = t >= kLag && t - kLag < T && w_s == nsteps - 1;
                 // stage boundary: the other stage is complete and this one is free to be overwritten.
                 // A tile end synchronises too (its bookkeeping below needs every wave's epilogue done).
-                if (kBarrierEveryStep || (sub == kQS - 1 && !CODD_EXP_NO_BARRIER) || wg_tile_end) __syncthreads();
+                if (kBarrierEveryStep || (sub == kQS - 1 && !CODD_EXP_NO_BARRIER && !RES) || wg_tile_end) __syncthreads();
                 if (MODE == MODE_FILTER && wg_tile_end) {
                     // empty the workgroup's hit list once it is half full
                     const unsigned cnt = lds_w[256];

@@ -178,7 +178,8 @@ int codd_knn_ivf_search(codd_knn_index* index, const float* dev_queries, int B, 
  *            badly — error norm above 0.04 — keeps the bf16 filter; so does, for the next
  *            "shadow8_cooldown" (256) searches, an index whose int8 passes leave more than
  *            "shadow8_max_surv" (4000) survivors per query or send queries to the fallback: dense
- *            clusters), "sample_div8" (20);
+ *            clusters), "sample_div8" (20), "resident_q" (1: rows of <= 512 int8 elements keep the
+ *            query block in LDS for the whole launch);
  *            "profile" = N keeps N (start, stop) HIP-event pairs, one per heavy-kernel launch,
  *            recorded on the launch stream (0 = off; resets the log)
  *   stats  : "searches", "scan_launches", "last_scan_blocks", "filter_passes",

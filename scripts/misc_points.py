@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from codd_query_engine_amd.knn_index import DeviceKnnIndex
 
-POINTS = [(10_000_000, 384, "f32", 256, 10), (10_000_000, 384, "f32", 1, 10), (12_500_000, 1024, "f16", 256, 10), (12_500_000, 1024, "f16", 1, 10),
+POINTS = [(10_000_000, 384, "f32", 256, 10), (10_000_000, 512, "f32", 256, 10), (10_000_000, 256, "f32", 256, 10), (10_000_000, 384, "f32", 64, 10), (10_000_000, 384, "f32", 1, 10), (12_500_000, 1024, "f16", 256, 10), (12_500_000, 1024, "f16", 1, 10),
           (10_000_000, 768, "f32", 256, 100), (10_000_000, 768, "bf16", 256, 10)]
 for rows, d, dtype, B, k in POINTS:
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -14,6 +14,7 @@ for rows, d, dtype, B, k in POINTS:
     for c0 in range(0, rows, 250_000):
         ix.upsert_device(c0, torch.randn((min(250_000, rows - c0), d), generator=g, device="cuda"))
     q = torch.randn((B, d), generator=g, device="cuda")
+    ix.set_option("resident_q", int(os.environ.get("CODD_RESIDENT_Q", "1")))
     for _ in range(3):
         ix.search_tensors(q, k)
     torch.cuda.synchronize()

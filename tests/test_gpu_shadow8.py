@@ -237,3 +237,32 @@ def test_rebuild_on_one_stream_is_awaited_by_searches_on_others(Index):
             assert np.array_equal(rr.cpu().numpy(), i_ref) and np.array_equal(dd.cpu().numpy(), d_ref)
     assert ix.stat("shadow8_builds") == 3  # one per round: the first one builds everything, the others only the appended rows
     ix.close()
+
+
+@pytest.mark.parametrize(
+    "n,d,B,k,dtype",
+    [
+        (70_000, 384, 256, 10, "f32"),   # MiniLM width: 3 int8 K-steps, the whole query block stays in LDS
+        (50_000, 512, 100, 10, "f32"),   # 4 K-steps: all four LDS slices hold a slice of their own
+        (40_000, 256, 32, 10, "bf16"),   # 2 K-steps
+        (30_000, 100, 7, 10, "f32"),     # 1 K-step (dpad8 = 128), ragged batch
+        (60_001, 384, 1, 100, "f16"),    # ragged last tile, single query, k = 100 (needs 2k sample tiles)
+    ],
+)
+def test_resident_query_block_is_exact(Index, n, d, B, k, dtype):
+    """Rows of <= 512 int8 elements: the query block is loaded into LDS once per workgroup and never re-staged
+    (gemm_filter_kernel<., ., 1, RES=1>).  Same bits as the oracle, and as the re-staging kernel."""
+    rng = np.random.default_rng(n + d + B)
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((B, d)).astype(np.float32)
+    ix = build8(Index, raw, dtype)
+    ix.set_option("shadow8_max_batch", 256)
+    dist, rows = ix.search(q, k)
+    assert ix.stat("shadow8_passes") == 1 and ix.stat("fallback_queries") == 0
+    rows_ref = o.to_storage(o.normalize_rows(raw), dtype)
+    d_ref, i_ref = o.search(rows_ref, dtype, o.normalize_rows(q), k)
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    ix.set_option("resident_q", 0)
+    dist2, rows2 = ix.search(q, k)
+    assert np.array_equal(rows2, rows) and np.array_equal(dist2, dist)
+    ix.close()

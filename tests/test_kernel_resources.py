@@ -26,7 +26,7 @@ def test_hot_kernels_do_not_spill():
     assert len(hot) >= 12, report
     for name in hot:
         assert rows[name]["scratch"] == 0 and rows[name]["spill"] == 0, f"{name} spills:\n{report}"
-    full = next(name for name in rows if "gemm_filter_kernel<0, 8, 0>" in name)
-    int8 = next(name for name in rows if "gemm_filter_kernel<0, 1, 1>" in name)  # the single-query latency kernel (int8 shadow)
+    full = next(name for name in rows if "gemm_filter_kernel<0, 8, 0, 0>" in name)
+    int8 = next(name for name in rows if "gemm_filter_kernel<0, 1, 1, 0>" in name)  # the single-query latency kernel (int8 shadow)
     assert rows[int8]["occ"] >= 2, report
     assert rows[full]["vgpr"] <= 256 and rows[full]["occ"] == 2, report
