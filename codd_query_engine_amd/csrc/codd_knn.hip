@@ -1175,6 +1175,9 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     const float* slack_q = use8 ? ix->qmeta + 256 : nullptr;  // int8: 2*eps per query, written by prep_queries8_kernel
     if (use8) ix->stat_shadow8_passes++;
     const bool resident = use8 && nsteps <= 4 && ix->resident_q;
+    // 65..128 queries only: with <= 64 the kernel is a byte stream (nothing to gain); with 8 query blocks the six-step body
+    // needs more than the 256 registers of a wave (hipcc spills, no gain measured)
+    const bool partial6 = use8 && nsteps == 6 && nq > 64 && nq <= 128 && ix->resident_q;
     const int64_t ntiles = (n + kTileRows - 1) / kTileRows;
     const int slots = k <= 64 ? 1 : 2;
     const float eps = filter_eps(ix);
@@ -1204,7 +1207,12 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
 #define CODD_LAUNCH_SAMPLE8R(NBQ)                                                                                            \
     hipLaunchKernelGGL((gemm_filter_kernel<MODE_SAMPLE, NBQ, 1, 1>), g, b, lds, st, shadow, qfrag, n, nsteps, ts, stride, \
                        nullptr, ix->bucket_max, nullptr, nullptr, 0, nullptr, nullptr, ix->rscale, ix->qmeta)
-        if (use8 && resident) {  // the whole int8 query block fits the LDS slices: loaded once per workgroup
+#define CODD_LAUNCH_SAMPLE8P(NBQ)                                                                                            \
+    hipLaunchKernelGGL((gemm_filter_kernel<MODE_SAMPLE, NBQ, 1, 2>), g, b, lds, st, shadow, qfrag, n, nsteps, ts, stride, \
+                       nullptr, ix->bucket_max, nullptr, nullptr, 0, nullptr, nullptr, ix->rscale, ix->qmeta)
+        if (use8 && partial6) {  // 768 int8 elements: two of the six query slices stay in LDS
+            CODD_LAUNCH_SAMPLE8P(4);
+        } else if (use8 && resident) {  // the whole int8 query block fits the LDS slices: loaded once per workgroup
             switch (nbq) {
                 case 1: CODD_LAUNCH_SAMPLE8R(1); break;
                 case 2: CODD_LAUNCH_SAMPLE8R(2); break;
@@ -1228,6 +1236,7 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
 #undef CODD_LAUNCH_SAMPLE
 #undef CODD_LAUNCH_SAMPLE8
 #undef CODD_LAUNCH_SAMPLE8R
+#undef CODD_LAUNCH_SAMPLE8P
     }
     HIP_TRY(hipGetLastError());
     {
@@ -1264,7 +1273,12 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
 #define CODD_LAUNCH_FILTER8R(NBQ)                                                                                           \
     hipLaunchKernelGGL((gemm_filter_kernel<MODE_FILTER, NBQ, 1, 1>), g, b, lds, st, shadow, qfrag, n, nsteps, ntiles, \
                        (int64_t)1, ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, nullptr, ix->rscale, ix->qmeta)
-        if (use8 && resident) {
+#define CODD_LAUNCH_FILTER8P(NBQ)                                                                                           \
+    hipLaunchKernelGGL((gemm_filter_kernel<MODE_FILTER, NBQ, 1, 2>), g, b, lds, st, shadow, qfrag, n, nsteps, ntiles, \
+                       (int64_t)1, ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, nullptr, ix->rscale, ix->qmeta)
+        if (use8 && partial6) {
+            CODD_LAUNCH_FILTER8P(4);
+        } else if (use8 && resident) {
             switch (nbq) {
                 case 1: CODD_LAUNCH_FILTER8R(1); break;
                 case 2: CODD_LAUNCH_FILTER8R(2); break;
@@ -1288,6 +1302,7 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
 #undef CODD_LAUNCH_FILTER
 #undef CODD_LAUNCH_FILTER8
 #undef CODD_LAUNCH_FILTER8R
+#undef CODD_LAUNCH_FILTER8P
     }
     HIP_TRY(hipGetLastError());
     const int nchunks = ix->dpad / elems_per_chunk(ix->dtype);

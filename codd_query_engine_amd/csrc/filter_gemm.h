@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
     typedef unsigned q4u __attribute__((ext_vector_type(4)));  // (native vectors: uint4 staging buffers end up as scratch allocas)
 #pragma unroll
     for (int sub = 0; sub < (RES ? 2 * kQS : kQS); ++sub) {
-        if (RES && sub >= nsteps) break;  // resident: slice s lives in LDS slice s for the whole kernel
+        if (RES == 1 && sub >= nsteps) break;  // resident: slice s lives in LDS slice s for the whole kernel
         const uint4* src = qfrag + (int64_t)q_s * kStagePieces + stid;
         uint4* dst = ldsQ + sub * kStagePieces + stid;
         q4u tmp[kQPn];
@@ -420,7 +420,14 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
     // SIMD", item 9).  Slice hazards with 4 LDS slices: interval t reads slices t-1 and t and writes slice t+2.
     // ------------------------------------------------------------------------------------------------------------
     constexpr int kLag = (CODD_STAGGER && MODE == MODE_FILTER && kKS == 2 && !RES) ? 1 : 0;
-    constexpr bool kNoStage = CODD_EXP_NO_QSTAGE || RES;
+    constexpr bool kNoStage = CODD_EXP_NO_QSTAGE || RES == 1;
+    // RES = 2 (launched only for rows of exactly 6 K-steps: 768 int8 elements): slices 0 and 1 stay in LDS slices 0 and 1,
+    // slices 2..5 alternate between LDS slices 2 and 3.  The unrolled body is one whole tile (6 steps), so which step
+    // stages what is known at compile time (a runtime choice would make hipcc drain the corpus prefetch at every join):
+    //   step 3 stages slice 4 -> LDS slice 2, step 4: 5 -> 3, step 5: 2 (of the next tile) -> 2, step 0: 3 -> 3,
+    //   steps 1 and 2 stage nothing; barriers behind steps 2, 3, 4 and 5.  4 staged slices per tile instead of 6.
+    constexpr int kBody = RES == 2 ? 6 : kUnroll;
+    static_assert(RES != 2 || (kRing == 3 && kQD == 1 && kQS == 2), "the 6-step body assumes the default ring and stages");
     constexpr bool kBarrierEveryStep = kLag == 1;
     constexpr int kNqbRun = (CODD_EXP_NB < NBQ ? CODD_EXP_NB : NBQ) * kQBper32 / kQSplit;
     const int TI = T + kLag;  // intervals
@@ -579,7 +586,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
     // unconditional
     auto run = [&](auto LAG) __attribute__((always_inline)) {
         constexpr int lag = decltype(LAG)::value;
-        for (int t0 = 0; t0 < TI; t0 += kUnroll) {
+        for (int t0 = 0; t0 < TI; t0 += kBody) {
             // one interval; IU (position inside the unrolled body) is a compile-time constant, so every register
             // buffer (corpus ring slot, query staging buffer) is chosen by the front end, not by an optimisation pass
             auto k_step = [&](auto IU) __attribute__((always_inline)) {
@@ -587,10 +594,14 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                 constexpr int i = iu % kRing;
                 const int t = t0 + iu;
                 const int stage = t / kQS, sub = t % kQS;
+                // RES = 2: iu IS the step inside the tile; what this step stages (slice, LDS slice) or nothing
+                constexpr int kStageSlice = iu == 3 ? 4 : (iu == 4 ? 5 : (iu == 5 ? 2 : (iu == 0 ? 3 : -1)));
+                constexpr int kStageSlot = iu == 3 ? 2 : (iu == 4 ? 3 : (iu == 5 ? 2 : 3));
+                constexpr bool kStagesHere = RES == 2 ? kStageSlice >= 0 : !kNoStage;
                 // query slice of step t+kQS: issue now, write to LDS at the end of the interval
                 {
-                    const uint4* src = qfrag + (int64_t)q_s * kStagePieces + stid;
-                    if (!kNoStage) {
+                    const uint4* src = qfrag + (int64_t)(RES == 2 ? (kStageSlice < 0 ? 0 : kStageSlice) : q_s) * kStagePieces + stid;
+                    if (kStagesHere) {
 #pragma unroll
                         for (int j = 0; j < kQPn; ++j) (iu % kQD ? qreg1 : qreg0)[j] = reinterpret_cast<const q4u*>(src)[j * kFilterThreads];
                     }
@@ -604,8 +615,10 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
 #if CODD_MFMA_PRIO
                     __builtin_amdgcn_s_setprio(1);
 #endif
+                    constexpr int kReadSlot6 = iu < 4 ? iu : iu - 2;  // RES = 2: slices 0..5 sit in LDS slices 0,1,2,3,2,3
                     mfma_part(std::integral_constant<int, i>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, kKS>{},
-                              RES ? ldsQ + c_s * kStagePieces + lane + qoff : slice_ptr(t));
+                              RES == 1 ? ldsQ + c_s * kStagePieces + lane + qoff
+                                       : (RES == 2 ? ldsQ + kReadSlot6 * kStagePieces + lane + qoff : slice_ptr(t)));
 #if CODD_MFMA_PRIO
                     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -613,7 +626,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                     // pin the step's shape: all 8 global loads (4 query, 4 corpus) first so they fly under the
                     // MFMAs; at most a few query fragments live (4 LDS reads up front, then one per MFMA);
                     // the LDS writes of the next query slice last
-                    __builtin_amdgcn_sched_group_barrier(0x020, 4 * kRB + (kNoStage ? 0 : kQPn), 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 4 * kRB + (kStagesHere ? kQPn : 0), 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
 #pragma unroll
                     for (int g = 0; g < kKS * kNqbRun - 4; ++g) {
@@ -621,11 +634,11 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     }
                     __builtin_amdgcn_sched_group_barrier(0x008, 4 * kRS, 0);
-                    if (!kNoStage) __builtin_amdgcn_sched_group_barrier(0x200, kQPn, 0);
+                    if (kStagesHere) __builtin_amdgcn_sched_group_barrier(0x200, kQPn, 0);
 #endif
                     {
-                        uint4* dstq = ldsQ + (((stage + 1) & 1) * kQS + sub) * kStagePieces + stid;
-                        if (!kNoStage) {
+                        uint4* dstq = ldsQ + (RES == 2 ? kStageSlot : ((stage + 1) & 1) * kQS + sub) * kStagePieces + stid;
+                        if (kStagesHere) {
 #pragma unroll
                             for (int j = 0; j < kQPn; ++j)
                                 reinterpret_cast<q4u*>(dstq)[j * kFilterThreads] = ((iu + kQD - 1) % kQD ? qreg1 : qreg0)[j];
@@ -688,7 +701,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                 const bool wg_tile_end = t >= kLag && t - kLag < T && w_s == nsteps - 1;
                 // stage boundary: the other stage is complete and this one is free to be overwritten.
                 // A tile end synchronises too (its bookkeeping below needs every wave's epilogue done).
-                if (kBarrierEveryStep || (sub == kQS - 1 && !CODD_EXP_NO_BARRIER && !RES) || wg_tile_end) __syncthreads();
+                if (kBarrierEveryStep || (sub == kQS - 1 && !CODD_EXP_NO_BARRIER && !RES) || (RES == 2 && iu >= 2) || wg_tile_end) __syncthreads();
                 if (MODE == MODE_FILTER && wg_tile_end) {
                     // empty the workgroup's hit list once it is half full
                     const unsigned cnt = lds_w[256];
@@ -715,7 +728,7 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                 }
                 if (t >= kLag && ++w_s == nsteps) { w_s = 0; w_u += step_u; }
             };
-            static_for<kUnroll>(k_step);
+            static_for<kBody>(k_step);
         }
     };
     if (kLag && __builtin_amdgcn_readfirstlane(wave) >= kFilterWaves / 2) run(std::integral_constant<int, 1>{});

@@ -266,3 +266,24 @@ def test_resident_query_block_is_exact(Index, n, d, B, k, dtype):
     dist2, rows2 = ix.search(q, k)
     assert np.array_equal(rows2, rows) and np.array_equal(dist2, dist)
     ix.close()
+
+
+def test_six_step_rows_with_two_resident_slices_are_exact(Index):
+    """768 int8 elements, 65..128 queries: gemm_filter_kernel<., 4, 1, RES=2> keeps two of the six query slices in LDS and
+    rings the other four; same bits as the oracle and as the re-staging kernel."""
+    rng = np.random.default_rng(12)
+    raw = rng.standard_normal((80_000, 768)).astype(np.float32)
+    ix = build8(Index, raw)
+    ix.set_option("shadow8_max_batch", 256)
+    rows_ref = o.normalize_rows(raw)
+    for B in (65, 100, 128):
+        q = rng.standard_normal((B, 768)).astype(np.float32)
+        dist, rows = ix.search(q, 10)
+        d_ref, i_ref = o.search(rows_ref, "f32", o.normalize_rows(q), 10)
+        assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+        ix.set_option("resident_q", 0)
+        dist2, rows2 = ix.search(q, 10)
+        ix.set_option("resident_q", 1)
+        assert np.array_equal(rows2, rows) and np.array_equal(dist2, dist)
+    assert ix.stat("fallback_queries") == 0
+    ix.close()
