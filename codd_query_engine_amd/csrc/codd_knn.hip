@@ -1467,14 +1467,14 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
 extern "C" {
 
 const char* codd_knn_version(void) {
-    return "codd_knn 0.4.0 gfx950"
+    return "codd_knn 0.5.0 gfx950"
 #if CODD_SHADOW_F16
            " shadow=f16"
 #else
            " shadow=bf16"
 #endif
 #if CODD_MFMA16
-           " mfma=16x16x32";
+           " mfma=16x16x32 int8=16x16x64";
 #else
            " mfma=32x32x16";
 #endif
