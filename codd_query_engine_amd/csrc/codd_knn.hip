@@ -373,54 +373,70 @@ __device__ __forceinline__ uint32_t quantize4(const float (&v)[4], float inv_sca
     }
     return packed;
 }
+// One workgroup quantises 16 consecutive rows (one 16-row MFMA block; 4 rows per wave, each row read once and kept in
+// registers between the max pass and the rounding), collects them in LDS and writes the block's pieces out in fragment
+// order: 16 consecutive lanes = the 16 rows of one piece column = 256 contiguous bytes (a wave per row writing its own
+// 16-byte pieces, 256 bytes apart, ran at a tenth of the HBM rate).
 template <int DT>
-__global__ __launch_bounds__(256) void shadow8_from_rows_kernel(const void* __restrict__ rows_, int64_t first, int64_t n, int dpad, int dpad8,
-                                                                uint32_t* __restrict__ shadow8, float* __restrict__ rscale,
+__global__ __launch_bounds__(256) void shadow8_from_rows_kernel(const void* __restrict__ rows_, int64_t first16, int64_t n, int dpad, int dpad8,
+                                                                uint4* __restrict__ shadow8, float* __restrict__ rscale,
                                                                 unsigned* __restrict__ eps_r_bits) {
-    const int lane = lane_id();
-    const int64_t r0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r0 >= n) return;
-    const int64_t row = first + r0;
+    constexpr int kRowDwords = 516;  // 512 + 4: sixteen rows read column-wise hit 64 different banks
+    __shared__ __attribute__((aligned(16))) uint32_t tile[16 * kRowDwords];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const int64_t row16 = first16 + (int64_t)blockIdx.x * 16;
     const int nch = dpad >> 2, nch8 = dpad8 >> 2, nsteps8 = dpad8 >> 7;
-    float vmax = 0.0f;
-    for (int j = lane; j < nch; j += kWave) {
-        float v[4];
-        if (DT == DT_F32) {
-            const float4 x = reinterpret_cast<const float4*>(rows_)[row * (int64_t)nch + j];
-            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-        } else {
-            const uint2 x = reinterpret_cast<const uint2*>(rows_)[row * (int64_t)nch + j];
-            const uint16_t hb[4] = {(uint16_t)(x.x & 0xffffu), (uint16_t)(x.x >> 16), (uint16_t)(x.y & 0xffffu), (uint16_t)(x.y >> 16)};
+    constexpr int kMaxIt = 8;  // <= 8 chunks of 4 elements per lane: rows of up to 2048 elements
+    float wave_err = 0.0f;     // largest error norm among this wave's rows
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = wave * 4 + rr;
+        const int64_t row = row16 + r;
+        float v[kMaxIt][4];
+        float vmax = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = DT == DT_BF16 ? __uint_as_float((uint32_t)hb[e] << 16) : f16_bits_to_f32(hb[e]);
-        }
+        for (int it = 0; it < kMaxIt; ++it) {
+            const int j = lane + kWave * it;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fabsf(v[e]));
-    }
-    vmax = butterfly_max(vmax);
-    const float scale = vmax > 0.0f ? vmax / 127.0f : 1.0f, inv_scale = 1.0f / scale;
-    float err2 = 0.0f;
-    for (int j = lane; j < nch8; j += kWave) {
-        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (j < nch) {
-            if (DT == DT_F32) {
-                const float4 x = reinterpret_cast<const float4*>(rows_)[row * (int64_t)nch + j];
-                v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-            } else {
-                const uint2 x = reinterpret_cast<const uint2*>(rows_)[row * (int64_t)nch + j];
-                const uint16_t hb[4] = {(uint16_t)(x.x & 0xffffu), (uint16_t)(x.x >> 16), (uint16_t)(x.y & 0xffffu), (uint16_t)(x.y >> 16)};
+            for (int e = 0; e < 4; ++e) v[it][e] = 0.0f;
+            if (j < nch && row < n) {
+                if (DT == DT_F32) {
+                    const float4 x = reinterpret_cast<const float4*>(rows_)[row * (int64_t)nch + j];
+                    v[it][0] = x.x; v[it][1] = x.y; v[it][2] = x.z; v[it][3] = x.w;
+                } else {
+                    const uint2 x = reinterpret_cast<const uint2*>(rows_)[row * (int64_t)nch + j];
+                    const uint16_t hb[4] = {(uint16_t)(x.x & 0xffffu), (uint16_t)(x.x >> 16), (uint16_t)(x.y & 0xffffu), (uint16_t)(x.y >> 16)};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = DT == DT_BF16 ? __uint_as_float((uint32_t)hb[e] << 16) : f16_bits_to_f32(hb[e]);
+                    for (int e = 0; e < 4; ++e) v[it][e] = DT == DT_BF16 ? __uint_as_float((uint32_t)hb[e] << 16) : f16_bits_to_f32(hb[e]);
+                }
             }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fabsf(v[it][e]));
         }
-        // elements [4j, 4j+4) = dword (j & 3) of the 16-byte piece c16 = j >> 2
-        shadow8[codd::shadow_piece_index(row, j >> 2, nsteps8) * 4 + (j & 3)] = quantize4(v, inv_scale, scale, err2);
+        vmax = butterfly_max(vmax);
+        const float scale = vmax > 0.0f ? vmax / 127.0f : 1.0f, inv_scale = 1.0f / scale;
+        float err2 = 0.0f;
+#pragma unroll
+        for (int it = 0; it < kMaxIt; ++it) {
+            const int j = lane + kWave * it;
+            if (j < nch8) tile[r * kRowDwords + j] = quantize4(v[it], inv_scale, scale, err2);  // (rows past n, chunks past the row: zeros)
+        }
+        err2 = butterfly_sum(err2);
+        if (row < n) {
+            if (lane == 0) rscale[row] = scale;
+            wave_err = fmaxf(wave_err, __builtin_sqrtf(err2) * 1.0001f + 1e-7f);  // inflated a little: the norm itself was accumulated in fp32
+        }
     }
-    err2 = butterfly_sum(err2);
+    // one device-scope atomic per workgroup at most, and only when it would raise the maximum (a single address hit by
+    // one atomic per row made this kernel 10x slower than its bytes); non-negative floats order as their bits
     if (lane == 0) {
-        rscale[row] = scale;
-        // inflated a little: the norm itself was accumulated in fp32
-        atomicMax(eps_r_bits, __float_as_uint(__builtin_sqrtf(err2) * 1.0001f + 1e-7f));  // non-negative floats order as their bits
+        const unsigned bits = __float_as_uint(wave_err);
+        if (bits > *reinterpret_cast<volatile unsigned*>(eps_r_bits)) atomicMax(eps_r_bits, bits);
+    }
+    __syncthreads();
+    // piece (c16, r) of the block: 16 bytes of row r at byte 16*c16
+    for (int p = (int)threadIdx.x; p < 16 * (dpad8 >> 4); p += 256) {
+        const int r = p & 15, c16 = p >> 4;
+        shadow8[codd::shadow_piece_index(row16 + r, c16, nsteps8)] = *reinterpret_cast<const uint4*>(&tile[r * kRowDwords + c16 * 4]);
     }
 }
 
@@ -1140,13 +1156,17 @@ int ensure_shadow8(codd_knn_index* ix, hipStream_t st) {
     }
     if (!ix->shadow8_ready) HIP_TRY(hipEventCreateWithFlags(&ix->shadow8_ready, hipEventDisableTiming));
     if (m > 0) {
-        // an update only ever raises *eps_r (the bound stays valid for rows that have been overwritten since)
-        const dim3 grid((unsigned)((m + 3) / 4)), block(256);
-        uint32_t* s8 = reinterpret_cast<uint32_t*>(ix->shadow8);
+        // an update only ever raises *eps_r (the bound stays valid for rows that have been overwritten since).
+        // Whole 16-row blocks: rows next to the dirty range are simply quantised again (same bytes).
+        const int64_t last = first + m;
+        first = first / 16 * 16;
+        m = (last + 15) / 16 * 16 - first;
+        const dim3 grid((unsigned)(m / 16)), block(256);
+        uint4* s8 = ix->shadow8;
         switch (ix->dtype) {
-            case DT_F32: hipLaunchKernelGGL(shadow8_from_rows_kernel<DT_F32>, grid, block, 0, st, ix->rows, first, m, ix->dpad, dpad8, s8, ix->rscale, ix->eps_r_bits); break;
-            case DT_BF16: hipLaunchKernelGGL(shadow8_from_rows_kernel<DT_BF16>, grid, block, 0, st, ix->rows, first, m, ix->dpad, dpad8, s8, ix->rscale, ix->eps_r_bits); break;
-            default: hipLaunchKernelGGL(shadow8_from_rows_kernel<DT_F16>, grid, block, 0, st, ix->rows, first, m, ix->dpad, dpad8, s8, ix->rscale, ix->eps_r_bits); break;
+            case DT_F32: hipLaunchKernelGGL(shadow8_from_rows_kernel<DT_F32>, grid, block, 0, st, ix->rows, first, n, ix->dpad, dpad8, s8, ix->rscale, ix->eps_r_bits); break;
+            case DT_BF16: hipLaunchKernelGGL(shadow8_from_rows_kernel<DT_BF16>, grid, block, 0, st, ix->rows, first, n, ix->dpad, dpad8, s8, ix->rscale, ix->eps_r_bits); break;
+            default: hipLaunchKernelGGL(shadow8_from_rows_kernel<DT_F16>, grid, block, 0, st, ix->rows, first, n, ix->dpad, dpad8, s8, ix->rscale, ix->eps_r_bits); break;
         }
         HIP_TRY(hipGetLastError());
     }
