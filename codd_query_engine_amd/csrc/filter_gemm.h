@@ -241,6 +241,9 @@ __device__ __forceinline__ void flush_hits(const unsigned* lds_hits, unsigned m,
 #ifndef CODD_BALLOT_HITS
 #define CODD_BALLOT_HITS 0   // 1: the epilogue reserves LDS hit slots per accumulator block (ballots) instead of per register; measured 2 % slower
 #endif
+#ifndef CODD_BINNED_INLOOP
+#define CODD_BINNED_INLOOP 0  // 1: the flushes inside the loop reserve per-query ranges too (int8 kernel -1 %, bf16 kernel +10 % time: register allocation; off)
+#endif
 #ifndef CODD_BINNED_FLUSH
 #define CODD_BINNED_FLUSH 1
 #endif
@@ -707,7 +710,12 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                     const unsigned cnt = lds_w[256];
                     __syncthreads();  // everyone has read cnt before the next epilogue can move it
                     if (cnt > (unsigned)(CODD_FLUSH_AT)) {
+#if CODD_BINNED_INLOOP
+                        // (scratch: the 256 free words behind the thresholds and the counter)
+                        flush_hits_binned(lds_hits, cnt < (unsigned)kHitCap ? cnt : (unsigned)kHitCap, tid, lds_w + 320, hits, hit_cnt, cap_q);
+#else
                         flush_hits(lds_hits, cnt < (unsigned)kHitCap ? cnt : (unsigned)kHitCap, tid, hits, hit_cnt, cap_q);
+#endif
                         __syncthreads();
                         if (tid == 0) lds_w[256] = 0u;
                         __syncthreads();
