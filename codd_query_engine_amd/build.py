@@ -20,7 +20,7 @@ _ROOT = os.path.dirname(_PKG)
 CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.path.join(CSRC, "libcodd_knn.so")
 SOURCES = ["codd_knn.hip"]
-HEADERS = ["wave_topk.h", "row_traits.h", "filter_gemm.h", os.path.join(_ROOT, "include", "codd_knn.h")]
+HEADERS = ["wave_topk.h", "row_traits.h", "filter_gemm.h", "filter_i8.h", os.path.join(_ROOT, "include", "codd_knn.h")]
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",

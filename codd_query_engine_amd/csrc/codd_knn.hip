@@ -27,6 +27,7 @@
 
 #include "codd_knn.h"
 #include "filter_gemm.h"
+#include "filter_i8.h"
 #include "row_traits.h"
 #include "wave_topk.h"
 
@@ -672,6 +673,7 @@ struct codd_knn_index : WorkBufs {
     int shadow8_enabled = 1;
     int shadow8_max_batch = 256;  // batches up to this size (one query pass) take the int8 filter
     int resident_q = 1;           // rows of <= 512 int8 elements: the query block stays in LDS ("resident_q" option)
+    int i8v2 = 1;                 // full query blocks on rows of > 512 elements take i8_tile_kernel (filter_i8.h); 2: from 384 elements on; 0: never
     int sample_div8 = 20;         // its thresholds come from a larger sample (the int8 slack is ~5x the bf16 one)
     uint4* shadow8 = nullptr;
     int64_t shadow8_rows = 0;     // rows the allocation covers (multiple of 256)
@@ -681,7 +683,7 @@ struct codd_knn_index : WorkBufs {
     int64_t dirty_lo = 0, dirty_hi = 0;  // rows written since the int8 shadow was last brought up to date: [lo, hi)
     hipStream_t shadow8_stream = nullptr;  // the stream the last rebuild ran on, and its completion
     hipEvent_t shadow8_ready = nullptr;
-    int64_t stat_shadow8_builds = 0, stat_shadow8_passes = 0;
+    int64_t stat_shadow8_builds = 0, stat_shadow8_passes = 0, stat_i8v2_passes = 0;
     // the worst row's quantisation error, copied back asynchronously after every build: a corpus with badly
     // quantisable rows (one large element, many small ones) would make the int8 bound useless and send every small batch
     // to the exact-scan fallback, so such an index keeps the bf16 filter.  Performance only: never needed for exactness.
@@ -1018,8 +1020,10 @@ int exact_scan(codd_knn_index* ix, const float* qn, int nqueries, int k, uint32_
 // ---- filter path -----------------------------------------------------------------------------
 
 float filter_eps(const codd_knn_index* ix) {
-    // |approx - exact| for unit-norm q and c.  u = unit roundoff of the shadow element type
-    // (bf16: 2^-9, fp16: 2^-11):
+    // |approx - exact| for unit-norm q and c.  u = unit roundoff of the shadow element type under round-to-nearest:
+    // half the spacing of the significand grid relative to the value (bf16: 8 significant bits, spacing 2^-7 -> u = 2^-8;
+    // fp16: 11 significant bits -> u = 2^-11).  Round 1 shipped 2^-9 for bf16, half the true bound: a unit vector of 239
+    // equal entries scores 0.99286 against itself in bf16 (error 0.0071 > the old eps 0.0040):
     //   rounding  : (2u + u^2) when q and the stored row are both rounded (Cauchy-Schwarz over the
     //               element-wise relative errors); u when the stored rows already are exactly
     //               representable (bf16 rows under a bf16 shadow, f16 rows under an fp16 shadow);
@@ -1031,7 +1035,7 @@ float filter_eps(const codd_knn_index* ix) {
     const bool exact_rows = ix->dtype == DT_F16;
     const float subnormal = 2.0f * sqrtf((float)ix->dpad) * 2.9802322e-8f;
 #else
-    const float u = 0.001953125f;
+    const float u = 0.00390625f;
     const bool exact_rows = ix->dtype == DT_BF16;
     const float subnormal = 0.0f;
 #endif
@@ -1091,6 +1095,9 @@ int ensure_filter_workspace(codd_knn_index* ix) {
             (const void*)&gemm_filter_kernel<MODE_DUMP, 8>};
         for (const void* fn : fns)
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter_lds_bytes(MODE_FILTER)));
+        HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_FILTER, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_FILTER)));
+        HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_FILTER, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_FILTER)));
+        HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_SAMPLE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_SAMPLE)));
         attr_set.store(true, std::memory_order_release);
     }
     return CODD_KNN_OK;
@@ -1170,6 +1177,12 @@ int ensure_shadow8(codd_knn_index* ix, hipStream_t st) {
         }
         HIP_TRY(hipGetLastError());
     }
+    {
+        // i8_tile_kernel reads whole tiles of scales: rows past the count carry NaN (`acc * NaN >= thr` is false for every
+        // threshold, so its epilogue needs no row < count test).  Rows appended later get real scales from the build above.
+        const int64_t pad = need - n;
+        if (pad > 0) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(ix->rscale + n), (int)0x7fc00000, (size_t)pad, st));
+    }
     HIP_TRY(hipEventRecord(ix->shadow8_ready, st));
     if (!ix->eps_r_host) {
         HIP_TRY(hipHostMalloc((void**)&ix->eps_r_host, sizeof(float), hipHostMallocDefault));
@@ -1212,6 +1225,9 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
 
     // sample: every `stride`-th tile
     const int nbq = nq <= 32 ? 1 : (nq <= 64 ? 2 : (nq <= 128 ? 4 : 8));  // 32-query blocks the GEMM multiplies
+    // full query blocks: the second-generation int8 kernel (filter_i8.h); rows whose query block fits the LDS keep the resident one
+    const bool tile_v2 = use8 && nbq == 8 && ((ix->i8v2 == 1 && !resident && nsteps >= 3) || (ix->i8v2 == 2 && nsteps >= 3));
+    if (tile_v2) ix->stat_i8v2_passes++;
     const int64_t ts = sample_tile_count(ix, ntiles, k, use8, nbq);
     const int64_t stride = ntiles / ts;
     {
@@ -1230,7 +1246,11 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
 #define CODD_LAUNCH_SAMPLE8P(NBQ)                                                                                            \
     hipLaunchKernelGGL((gemm_filter_kernel<MODE_SAMPLE, NBQ, 1, 2>), g, b, lds, st, shadow, qfrag, n, nsteps, ts, stride, \
                        nullptr, ix->bucket_max, nullptr, nullptr, 0, nullptr, nullptr, ix->rscale, ix->qmeta)
-        if (use8 && partial6) {  // 768 int8 elements: two of the six query slices stay in LDS
+        if (tile_v2) {
+            // (the sample pass keeps the generic program: its tile-structured instantiation spills inside the loop)
+            hipLaunchKernelGGL((i8_tile_kernel<MODE_SAMPLE, false>), g, b, i8_lds_bytes(MODE_SAMPLE), st, shadow, qfrag, n, nsteps, ts, stride, nullptr,
+                               ix->bucket_max, nullptr, nullptr, 0, nullptr, ix->rscale, ix->qmeta);
+        } else if (use8 && partial6) {  // 768 int8 elements: two of the six query slices stay in LDS
             CODD_LAUNCH_SAMPLE8P(4);
         } else if (use8 && resident) {  // the whole int8 query block fits the LDS slices: loaded once per workgroup
             switch (nbq) {
@@ -1296,7 +1316,14 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
 #define CODD_LAUNCH_FILTER8P(NBQ)                                                                                           \
     hipLaunchKernelGGL((gemm_filter_kernel<MODE_FILTER, NBQ, 1, 2>), g, b, lds, st, shadow, qfrag, n, nsteps, ntiles, \
                        (int64_t)1, ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, nullptr, ix->rscale, ix->qmeta)
-        if (use8 && partial6) {
+        if (tile_v2) {
+            if (nsteps % 3 == 0)
+                hipLaunchKernelGGL((i8_tile_kernel<MODE_FILTER, true>), g, b, i8_lds_bytes(MODE_FILTER), st, shadow, qfrag, n, nsteps, ntiles, (int64_t)1,
+                                   ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, ix->rscale, ix->qmeta);
+            else
+                hipLaunchKernelGGL((i8_tile_kernel<MODE_FILTER, false>), g, b, i8_lds_bytes(MODE_FILTER), st, shadow, qfrag, n, nsteps, ntiles, (int64_t)1,
+                                   ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, ix->rscale, ix->qmeta);
+        } else if (use8 && partial6) {
             CODD_LAUNCH_FILTER8P(4);
         } else if (use8 && resident) {
             switch (nbq) {
@@ -1875,6 +1902,11 @@ int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {
         ix->exp_slack_scale = (float)value / 100.0f;
         return CODD_KNN_OK;
     }
+    if (strcmp(key, "i8v2") == 0) {
+        if (value < 0 || value > 2) return fail(CODD_KNN_EINVAL, "i8v2 must be 0, 1 or 2%s");
+        ix->i8v2 = (int)value;
+        return CODD_KNN_OK;
+    }
     if (strcmp(key, "resident_q") == 0) {
         if (value != 0 && value != 1) return fail(CODD_KNN_EINVAL, "resident_q must be 0 or 1%s");
         ix->resident_q = (int)value;
@@ -1949,6 +1981,7 @@ int codd_knn_get_stat(const codd_knn_index* ix, const char* key, int64_t* out) {
     else if (strcmp(key, "filter_passes") == 0) *out = ix->stat_filter_passes;
     else if (strcmp(key, "shadow8_builds") == 0) *out = ix->stat_shadow8_builds;
     else if (strcmp(key, "shadow8_passes") == 0) *out = ix->stat_shadow8_passes;
+    else if (strcmp(key, "i8v2_passes") == 0) *out = ix->stat_i8v2_passes;
     else if (strcmp(key, "shadow8_cooldowns") == 0) *out = ix->stat_cooldowns;
     else if (strcmp(key, "shadow8_eps_r_micro") == 0) {  // worst row's quantisation error norm x 1e6, as last read back
         if (ix->eps_r_copied && hipEventQuery(ix->eps_r_copied) == hipSuccess) *out = (int64_t)(*ix->eps_r_host * 1e6f);

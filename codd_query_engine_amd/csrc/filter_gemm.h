@@ -224,11 +224,14 @@ __device__ __forceinline__ void static_for(F f) {
 }
 
 // append a workgroup's LDS hit list (entries: score bits, row, query) to the per-query global lists
+// qs (optional, LDS): per-query factor still to be applied to the stored scores (filter_i8.h stores acc * rscale and leaves
+// the query's scale to the flush)
 __device__ __forceinline__ void flush_hits(const unsigned* lds_hits, unsigned m, int tid, u64* __restrict__ hits,
-                                           unsigned* __restrict__ hit_cnt, int cap_q) {
+                                           unsigned* __restrict__ hit_cnt, int cap_q, const float* qs = nullptr) {
     for (unsigned e = tid; e < m; e += kFilterThreads) {
-        const float v = __uint_as_float(lds_hits[e * 3 + 0]);
         const unsigned row = lds_hits[e * 3 + 1], q = lds_hits[e * 3 + 2];
+        float v = __uint_as_float(lds_hits[e * 3 + 0]);
+        if (qs) v *= qs[q];
         const unsigned slot = atomicAdd(&hit_cnt[q * kHitCntStride], 1u);
         if (slot < (unsigned)cap_q) hits[(int64_t)q * cap_q + slot] = make_key(v, row);
     }
@@ -248,7 +251,7 @@ __device__ __forceinline__ void flush_hits(const unsigned* lds_hits, unsigned m,
 #define CODD_BINNED_FLUSH 1
 #endif
 __device__ __forceinline__ void flush_hits_binned(const unsigned* lds_hits, unsigned m, int tid, unsigned* cnt256,
-                                                  u64* __restrict__ hits, unsigned* __restrict__ hit_cnt, int cap_q) {
+                                                  u64* __restrict__ hits, unsigned* __restrict__ hit_cnt, int cap_q, const float* qs = nullptr) {
     constexpr int kPer = kHitCap / kFilterThreads;
     static_assert(kHitCap % kFilterThreads == 0, "hit list is a whole number of entries per thread");
     if (tid < 256) cnt256[tid] = 0u;
@@ -271,7 +274,9 @@ __device__ __forceinline__ void flush_hits_binned(const unsigned* lds_hits, unsi
         if (e < m) {
             const unsigned q = lds_hits[e * 3 + 2];
             const unsigned slot = cnt256[q] + rank[i];
-            if (slot < (unsigned)cap_q) hits[(int64_t)q * cap_q + slot] = make_key(__uint_as_float(lds_hits[e * 3 + 0]), lds_hits[e * 3 + 1]);
+            float v = __uint_as_float(lds_hits[e * 3 + 0]);
+            if (qs) v *= qs[q];
+            if (slot < (unsigned)cap_q) hits[(int64_t)q * cap_q + slot] = make_key(v, lds_hits[e * 3 + 1]);
         }
     }
 }

@@ -1,0 +1,452 @@
+// filter_i8.h — the int8 filter GEMM for full query blocks (more than 128 queries, rows of more than 256 elements),
+// second generation.  Same operands, same layouts, same hit lists as gemm_filter_kernel<MODE, 8, EL = 1> in
+// filter_gemm.h (which stays the kernel of every other shape); what changed is the schedule:
+//
+//   * round 1's loop compiled to `ds_read_b128 -> s_waitcnt lgkmcnt(0) -> 2 MFMA` 32 times per K-step with ONE query
+//     fragment register set: every MFMA pair paid a full LDS round trip (profiles/r2/i8_v1_isa_excerpt.txt; matrix pipe
+//     38 % busy, LDS array 26 % busy, waves parked 56 % of their cycles).  Here the query fragments run through a ring
+//     of kBD register sets and the order of a K-step is pinned;
+//   * the query slices go L2 -> LDS by LDS-DMA (buffer_load ... lds), not through 16 staging registers and ds_write: with
+//     128 accumulator and 48 corpus-ring registers the staging set pushed the wave over the 256 registers it has at two
+//     waves per SIMD (hipcc spilled, and every scratch reload waits vmcnt(0));
+//   * EVERY vector-memory operation of the loop is issued by inline asm and waited for by hand with counted vmcnt
+//     (the queue retires in order; per interval it receives, in this order: 1 scale load, 4 DMA, 4 corpus loads).
+//     hipcc sees no load in flight, so it inserts no wait of its own: with the DMA visible it ordered every LDS access
+//     it could see behind the youngest DMA, and a false register dependency on an in-flight load cost a vmcnt(0)
+//     inside the epilogue (measured: 5 us per tile).  The fragment reads of the MFMA phase are inline asm too, with
+//     counted lgkmcnt; values flow from each wait asm to their consumers as in/out operands;
+//   * waves 4..7 (the SIMD partners of waves 0..3) can run one K-step behind (CODD_I8_LAG), and a tile's epilogue is
+//     deferred to the start of the wave's next interval;
+//   * the epilogue tests a block pair in the integer domain first — max of the 8 accumulators of (2 row blocks x 1 query
+//     block) times the largest row scale of the wave's 32 rows against the query's threshold: 7 vector instructions per
+//     pair instead of 26 — and only pairs that can hold a hit take the exact per-row test (same expression as before,
+//     so the hit lists are the same);
+//   * row scales reach the epilogue through LDS (one small DMA per wave and interval), not through global loads inside a
+//     conditional region;
+//   * the workgroup's hit-list bookkeeping rides on the interval barrier: no extra barriers per tile.
+//
+// LDS: 4 query slices x 32 KiB | 832 bookkeeping words | 4 row-scale buffers x (256 + 16) floats | hit list.
+#pragma once
+#include "filter_gemm.h"
+
+namespace codd {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kI8SliceBytes = 32768;  // one 128-wide K slice of the 256-query block
+constexpr int kI8RsBufs = 4;          // row-scale buffers (tile ordinal & 3)
+constexpr int kI8RsStride = 272;      // floats per buffer: 256 row scales + 8 per-wave maxima (+ pad)
+#ifndef CODD_I8_BDEPTH
+#define CODD_I8_BDEPTH 4              // query-fragment register sets in flight
+#endif
+constexpr int kBD = CODD_I8_BDEPTH;
+#ifndef CODD_I8_LAG
+#define CODD_I8_LAG 0                 // 1: waves 4..7 run one K-step behind waves 0..3 (measured slower: an epilogue takes longer than the partner's MFMAs of one step, profiles/r2/i8_tile_ablation.txt)
+#endif
+
+// ---- hand-issued memory operations (see the header) --------------------------------------------------------------
+// buffer descriptor (4 SGPRs): base, 48-bit address | stride 0, bytes, gfx950 raw-buffer flags; out-of-range reads return 0
+__device__ __forceinline__ i32x4 i8_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    i32x4 r;  // (readfirstlane: the asm operands are SGPR tuples whatever hipcc's uniformity analysis concludes)
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+template <int OFF>
+__device__ __forceinline__ void i8_load_b128_nt(u32x4& dst, int voff, i32x4 rsrc) {  // read-once stream: non-temporal
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3 nt" : "=v"(dst) : "v"(voff), "s"(rsrc), "n"(OFF));
+}
+// 64 lanes x 16 bytes: global (rsrc + voff + soff) -> LDS [lds_addr + 16 * lane]
+__device__ __forceinline__ void i8_dma_b128(unsigned lds_addr, int voff, i32x4 rsrc, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rsrc),
+                 "s"(__builtin_amdgcn_readfirstlane(soff))
+                 : "memory");
+}
+// 64 lanes x 4 bytes: global (rsrc + voff + soff) -> LDS [lds_addr + 4 * lane]
+__device__ __forceinline__ void i8_dma_b32(unsigned lds_addr, int voff, i32x4 rsrc, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rsrc),
+                 "s"(__builtin_amdgcn_readfirstlane(soff))
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void i8_wait_vm(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128_asm(i32x4& dst, unsigned addr) {
+#ifdef CODD_I8_EXP_NOBREAD
+    asm volatile("; no read %0 %1 %2" : "=v"(dst) : "v"(addr), "n"(OFF));  // diagnostic: no LDS read at all
+#else
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+#endif
+}
+template <int N>
+__device__ __forceinline__ void lgkm_wait_asm(i32x4& v) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
+}
+
+// vector-memory operations per interval, in issue order: scale DMA, kDmaPerIv slice DMA, kAPerIv corpus loads
+constexpr int kDmaPerIv = 4, kAPerIv = 4, kOpsPerIv = 1 + kDmaPerIv + kAPerIv;
+// bookkeeping words behind the slices: [0..255] pre-test thresholds, transposed ([query & 15][query >> 4]); [256] hit count;
+// [320..575] query scales; [576..831] exact thresholds (thr / qscale), by query.  SAMPLE: [0..511] = 256 u64 keys.
+constexpr int kI8Words = 832;
+
+__host__ __device__ constexpr size_t i8_lds_bytes(int mode) {
+    return (size_t)4 * kI8SliceBytes + kI8Words * 4 + kI8RsBufs * kI8RsStride * 4 + (mode == MODE_FILTER ? (size_t)kHitCap * 12 : 0);
+}
+
+// STEPS3: the row has a multiple of 3 K-steps (the host picks the instantiation): tiles start at corpus-ring phase 0
+template <int MODE, bool STEPS3>
+__global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict__ shadow8, const uint4* __restrict__ qfrag8, int64_t n, int nsteps,
+                                                         int64_t ntiles_run, int64_t tile_stride, const float* __restrict__ thr,
+                                                         u64* __restrict__ bucket_key, u64* __restrict__ hits, unsigned* __restrict__ hit_cnt,
+                                                         int cap_q, unsigned* __restrict__ flags, const float* __restrict__ rscale,
+                                                         const float* __restrict__ qscale) {
+    static_assert(MODE == MODE_FILTER || MODE == MODE_SAMPLE, "filter and sample passes only");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* lds_w = reinterpret_cast<unsigned*>(smem + 4 * kI8SliceBytes);
+    float* lds_rs = reinterpret_cast<float*>(lds_w + kI8Words);                  // row scales of the tiles in flight
+    unsigned* lds_hits = reinterpret_cast<unsigned*>(lds_rs + kI8RsBufs * kI8RsStride);
+    u64* lds_k = reinterpret_cast<u64*>(lds_w);                                  // SAMPLE: best (score, row) key of the tile per query
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    const unsigned lds0 = (unsigned)(size_t)(lds_byte*)smem;                     // LDS byte address of the first query slice
+
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int64_t G = gridDim.x;
+    const int64_t first_u = blockIdx.x;
+    const int64_t my_tiles = ntiles_run > (int64_t)blockIdx.x ? (ntiles_run - blockIdx.x + G - 1) / G : 0;
+    const int T = (int)(my_tiles * nsteps);  // K-steps of this workgroup
+    if (T == 0) return;
+
+    if (MODE == MODE_FILTER) {
+        if (tid < 256) {
+            const float th = thr[tid] / qscale[tid];  // the test runs on acc * rscale[row]
+            // the pre-test (largest accumulator of a block pair x largest scale of the lane's rows) is only conclusive for a
+            // positive threshold: thresholds <= 0 (and NaN: a zero query) always take the exact per-row test
+            lds_w[(tid & 15) * 16 + (tid >> 4)] = __float_as_uint(th > 0.0f ? th : -INFINITY);
+            lds_w[576 + tid] = __float_as_uint(th);
+            lds_w[320 + tid] = __float_as_uint(qscale[tid]);
+        }
+        if (tid == 0) lds_w[256] = 0u;
+    } else {
+        if (tid < 256) lds_k[tid] = 0ull;
+    }
+
+    const int lane16 = lane * 16;
+    const i32x4 rsrc_q = i8_rsrc(qfrag8, (unsigned)(nsteps * kI8SliceBytes));
+    const int64_t step_bytes = 4096;                       // 4 pieces x 1 KiB: this wave's 32 rows x 128 elements
+    const int64_t tile_bytes = (int64_t)8 * nsteps * step_bytes;
+
+    i32x4 acc[2][16];
+#pragma unroll
+    for (int rs = 0; rs < 2; ++rs)
+#pragma unroll
+        for (int qb = 0; qb < 16; ++qb) acc[rs][qb] = i32x4{0, 0, 0, 0};
+
+    // ---- corpus fragments: HBM -> registers, ring of 3 K-steps, the cursor runs 2 steps ahead (1 for a lagging wave) ----
+    int64_t l_u = first_u;  // run-tile ordinal of the next step to load
+    int l_s = 0, l_left = T;
+    u32x4 ring[3][4];
+    auto load_a = [&](u32x4(&dst)[4]) __attribute__((always_inline)) {
+#ifdef CODD_I8_EXP_SAMETILE
+        const char* base = reinterpret_cast<const char*>(shadow8) + ((int64_t)wave * nsteps + l_s) * step_bytes;  // diagnostic: corpus served by L2
+#else
+        const char* base = reinterpret_cast<const char*>(shadow8) + (l_u * tile_stride) * tile_bytes + ((int64_t)wave * nsteps + l_s) * step_bytes;
+#endif
+        const i32x4 r = i8_rsrc(base, 4096);
+        i8_load_b128_nt<0>(dst[0], lane16, r);
+        i8_load_b128_nt<1024>(dst[1], lane16, r);
+        i8_load_b128_nt<2048>(dst[2], lane16, r);
+        i8_load_b128_nt<3072>(dst[3], lane16, r);
+        if (--l_left > 0) {  // past the last step the cursor stays on it: loads are unconditional
+            if (++l_s == nsteps) { l_s = 0; l_u += G; }
+        }
+    };
+
+    // ---- query slices: L2 -> LDS by LDS-DMA, slice of step t in LDS slice t & 3, requested two intervals ahead ----
+    // wave w moves the 1 KiB chunks 8j + w (j = 0..3) of a slice: 64 lanes x 16 bytes each, contiguous on both sides
+    int q_s = 0;
+    auto stage_dma = [&](int slot) __attribute__((always_inline)) {
+        const int soff = q_s * kI8SliceBytes + wave * 1024;
+        const unsigned dst = lds0 + (unsigned)(slot * kI8SliceBytes + wave * 1024);
+#pragma unroll
+        for (int j = 0; j < kDmaPerIv; ++j) i8_dma_b128(dst + j * 8192, lane16, rsrc_q, soff + j * 8192);
+        q_s = q_s + 1 == nsteps ? 0 : q_s + 1;
+    };
+
+    // ---- row scales of run-tile ordinal u (this workgroup's tile number `ord`) -> LDS buffer ord & 3, by DMA too ----
+    // one 256-byte DMA per wave and interval: the scales of rows [r0, r0 + 64) of the tile, r0 = min(32 wave, 192) — the
+    // wave's own 32 rows among them (neighbouring waves write the same bytes twice).  Every interval of a tile repeats
+    // the request (same bytes): the number of operations per interval stays fixed, which the counted waits rely on.
+    // The host keeps rscale[r] = NaN for count <= r < the next multiple of 256: `acc * NaN >= thr` is false for every
+    // threshold, so the epilogue needs no row < n test; tiles past the corpus (padding intervals) read zeros.
+    const int lane4 = lane * 4;
+    auto rs_dma = [&](int64_t u, int ord) __attribute__((always_inline)) {
+        const int64_t row0 = u * tile_stride * kTileRows;
+        const int64_t bound = (n + kTileRows - 1) / kTileRows * kTileRows;
+        const int64_t left = bound - row0;
+        const int rows_here = left >= kTileRows ? kTileRows : (left > 0 ? (int)left : 0);
+        const int r0 = wave * 32 < 192 ? wave * 32 : 192;
+        i8_dma_b32(lds0 + (unsigned)(4 * kI8SliceBytes + kI8Words * 4 + ((ord & 3) * kI8RsStride + r0) * 4), lane4,
+                   i8_rsrc(rscale + (left > 0 ? row0 : 0), (unsigned)(rows_here * 4)), r0 * 4);
+    };
+
+    // ---- epilogues ----
+    auto epilogue = [&](int64_t cu, int ord) __attribute__((always_inline)) {
+        // lane coordinates re-derived behind an opaque asm: hipcc otherwise hoists every per-query-block address of this
+        // body out of the interval loop and keeps dozens of registers of loop invariants alive across the MFMA phases
+        int c = lane & 15, lg = lane >> 4;
+        asm volatile("" : "+v"(c), "+v"(lg));
+        const int64_t tile = cu * tile_stride;
+        const float* rsb = lds_rs + (ord & 3) * kI8RsStride;
+        const unsigned row0 = (unsigned)(tile * kTileRows) + (unsigned)(wave * 32 + 4 * lg);  // + 16 * rs + r
+        const f32x4 rsc0 = *reinterpret_cast<const f32x4*>(rsb + wave * 32 + 4 * lg);
+        const f32x4 rsc1 = *reinterpret_cast<const f32x4*>(rsb + wave * 32 + 16 + 4 * lg);
+#ifdef CODD_I8_EXP_NOEPI
+        if (true) {
+#pragma unroll
+            for (int qb = 0; qb < 16; ++qb) { asm volatile("" ::"v"(acc[0][qb])); asm volatile("" ::"v"(acc[1][qb])); }
+        } else if (false) {
+#else
+        if (MODE == MODE_FILTER) {
+#endif
+            // the lane's 16 pre-test thresholds (queries 16 qb + c) in four reads, and the largest scale among its 8 rows
+            // (NaN scales of rows past n drop out of the maximum)
+            f32x4 thp4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) thp4[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(lds_w) + c * 16 + 4 * j);
+            const float rsl = fmaxf(fmaxf(fmaxf(rsc0[0], rsc0[1]), fmaxf(rsc0[2], rsc0[3])), fmaxf(fmaxf(rsc1[0], rsc1[1]), fmaxf(rsc1[2], rsc1[3])));
+#pragma unroll
+            for (int qb = 0; qb < 16; ++qb) {
+                const i32x4 a0 = acc[0][qb], a1 = acc[1][qb];
+                const int m = max(max(max(a0[0], a0[1]), max(a0[2], a0[3])), max(max(a1[0], a1[1]), max(a1[2], a1[3])));
+                // no accumulator of the pair reaches the threshold when the largest one times the lane's largest scale does
+                // not (a positive accumulator times a smaller scale is smaller, rounding is monotone, a non-positive one
+                // is below a positive threshold anyway)
+                const float thp = thp4[qb >> 2][qb & 3];
+                if (__builtin_expect(__any((float)m * rsl >= thp), 0)) {
+                    const unsigned q = (unsigned)(qb * 16 + c);
+                    const float th = thp == -INFINITY ? __uint_as_float(lds_w[576 + q]) : thp;  // (the exact threshold when it is not positive)
+                    float v[8];
+                    bool hit[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        v[i] = (float)(i < 4 ? a0[i] : a1[i - 4]) * (i < 4 ? rsc0[i] : rsc1[i - 4]);  // the first-generation kernel's expression
+                        hit[i] = v[i] >= th;
+                    }
+                    if (__any(hit[0] | hit[1] | hit[2] | hit[3] | hit[4] | hit[5] | hit[6] | hit[7])) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            if (hit[i]) {
+                                const unsigned slot = atomicAdd(&lds_w[256], 1u);
+                                if (slot < (unsigned)kHitCap) {
+                                    lds_hits[slot * 3 + 0] = __float_as_uint(v[i]);   // (the query's scale is applied by the flush)
+                                    lds_hits[slot * 3 + 1] = row0 + (unsigned)(16 * (i >> 2) + (i & 3));
+                                    lds_hits[slot * 3 + 2] = q;
+                                } else {
+                                    // workgroup list full (a dense cluster many queries point at): this query's candidates
+                                    // are incomplete -> poison its counter, finalize sends exactly this query to the next stage
+                                    atomicOr(&hit_cnt[q * kHitCntStride], 0x80000000u);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            const bool ragged = (tile + 1) * kTileRows > n;
+#pragma unroll
+            for (int qb = 0; qb < 16; ++qb) {
+                u64 best = 0ull;  // this lane's best (score, row) of the pair; ties -> lower row, as everywhere
+#pragma unroll
+                for (int rs = 0; rs < 2; ++rs)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned row = row0 + (unsigned)(16 * rs + r);
+                        if (!ragged || (int64_t)row < n) {
+                            const u64 key = make_key((float)acc[rs][qb][r] * (rs ? rsc1[r] : rsc0[r]), row);
+                            best = key > best ? key : best;
+                        }
+                    }
+                atomicMax(reinterpret_cast<unsigned long long*>(&lds_k[qb * 16 + c]), (unsigned long long)best);
+            }
+        }
+        if (!(STEPS3 && !CODD_I8_LAG)) {  // (the tile-structured program starts every tile from zero accumulators instead)
+#pragma unroll
+            for (int rs = 0; rs < 2; ++rs)
+#pragma unroll
+                for (int qb = 0; qb < 16; ++qb) acc[rs][qb] = i32x4{0, 0, 0, 0};
+        }
+    };
+
+    // MFMAs of one K-step: corpus fragments in ring slot SLOT, query slice at LDS byte address qaddr (+ lane * 16).  32
+    // groups (K half ks, query block qb) of 2 MFMAs; the fragment of group g + kBD is requested when group g has
+    // consumed its register set.  Before group g the reads of groups g+1 .. min(31, g + kBD - 1) are the only younger
+    // LGKM operations and LDS returns in order, hence lgkmcnt(that many).  FIRST: the first K-step of a tile starts its
+    // accumulators from zero (no clearing pass after the epilogue).
+    auto mfma_step = [&](auto SLOT, auto FIRST, unsigned qaddr) __attribute__((always_inline)) {
+        constexpr int slot = decltype(SLOT)::value;
+        constexpr bool first = decltype(FIRST)::value;
+        i32x4 b[kBD];
+        static_for<kBD>([&](auto G_) __attribute__((always_inline)) {
+            constexpr int g = decltype(G_)::value;
+            lds_read_b128_asm<(((g & 15) * 2) + (g >> 4)) * 1024>(b[g], qaddr);
+        });
+        static_for<32>([&](auto G_) __attribute__((always_inline)) {
+            constexpr int g = decltype(G_)::value, ks = g >> 4, qb = g & 15;
+            constexpr int younger = (g + kBD - 1 < 31 ? g + kBD - 1 : 31) - g;
+            lgkm_wait_asm<younger>(b[g % kBD]);
+            const i32x4 a0 = __builtin_bit_cast(i32x4, ring[slot][0 * 2 + ks]);
+            const i32x4 a1 = __builtin_bit_cast(i32x4, ring[slot][1 * 2 + ks]);
+            const i32x4 zero = {0, 0, 0, 0};
+            acc[0][qb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b[g % kBD], first && ks == 0 ? zero : acc[0][qb], 0, 0, 0);
+            acc[1][qb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b[g % kBD], first && ks == 0 ? zero : acc[1][qb], 0, 0, 0);
+            if constexpr (g + kBD < 32) {
+                constexpr int g2 = g + kBD;
+                lds_read_b128_asm<(((g2 & 15) * 2) + (g2 >> 4)) * 1024>(b[g % kBD], qaddr);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    // ---- the interval loop ----
+    // interval t: waves 0..3 run step t, waves 4..7 step t - LAG; every wave requests its share of slice t + 2 and loads
+    // the scales of step t's tile; one barrier.  Slices read: t & 3 and (t - 1) & 3; landing: (t + 1) & 3, (t + 2) & 3.
+    // Issue order per interval: [a pending epilogue], scale DMA, slice DMA, corpus loads, MFMAs, barrier.  Waits (operations
+    // younger than the one waited for, in queue order):
+    //   corpus step loaded in interval t-2, at the MFMAs of t : everything of t-1 and of t                  = 2 kOpsPerIv
+    //   DMA of interval t-1, at the barrier of t : the corpus loads of t-1 and everything of t              = kAPerIv + kOpsPerIv
+    auto run = [&](auto LAG_) __attribute__((always_inline)) {
+        constexpr int LAG = decltype(LAG_)::value;
+        rs_dma(first_u, 0);  // (the first tile's scales)
+        stage_dma(0);
+        stage_dma(1);
+        // corpus prologue: a lagging wave starts with step "-1" on an all-zero ring slot
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) ring[2][kk] = u32x4{0u, 0u, 0u, 0u};
+        load_a(ring[0]);
+        if (LAG == 0) load_a(ring[1]);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // slices 0, 1, the first scales and corpus steps have landed
+
+        int64_t c_u = first_u;   // compute cursor (this wave's step s = t - LAG)
+        int c_s = 0, c_ord = 0;
+        int64_t w_u = first_u;   // workgroup cursor (step t)
+        int w_s = 0, w_ord = 0;
+        bool pending = false;    // a finished tile whose epilogue has not run yet
+        int64_t p_u = 0;
+        int p_ord = 0;
+        int pub_ord = 0;         // SAMPLE: next tile ordinal to publish
+        const int TI = T + (CODD_I8_LAG ? 1 : 0);
+        // one interval; IU (= t mod 3) picks the corpus ring slots statically.  EPI: a pending epilogue may run inside
+        // (the generic loop); the tile-structured loop below runs it between intervals instead.
+        // (A loop that is not unrolled, with a uniform switch around three static copies of [loads, wait, MFMAs], made
+        // hipcc merge the 128 accumulator registers across the arms with copies: 700 bytes of scratch.)
+        auto interval = [&](auto IU, auto EPI, auto FIRST, int t) __attribute__((always_inline)) {
+            constexpr int iu = decltype(IU)::value;
+            constexpr int ci = (iu + 3 - LAG) % 3, li = (ci + 2) % 3;
+            if (decltype(EPI)::value && pending) {
+                epilogue(p_u, p_ord);
+                pending = false;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            rs_dma(w_u, w_ord);
+#ifndef CODD_I8_EXP_NODMA
+            stage_dma((t + 2) & 3);
+#endif
+            const unsigned qaddr = lds0 + (unsigned)(((t - LAG) & 3) * kI8SliceBytes + lane16);
+            load_a(ring[li]);
+            i8_wait_vm<2 * kOpsPerIv>(ring[ci][0], ring[ci][1], ring[ci][2], ring[ci][3]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_step(std::integral_constant<int, ci>{}, FIRST, qaddr);
+            const int s = t - LAG;
+            if (s >= 0) {
+                if (s < T && c_s == nsteps - 1) { pending = true; p_u = c_u; p_ord = c_ord; }
+                if (++c_s == nsteps) { c_s = 0; c_u += G; ++c_ord; }
+            }
+#ifdef CODD_I8_EXP_NOBARRIER
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kAPerIv + kOpsPerIv) : "memory");  // diagnostic (racy)
+#else
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kAPerIv + kOpsPerIv) : "memory");
+#endif
+            // every wave has folded tile w_ord - 1 by the end of the interval with w_s == 1, and no epilogue runs in the
+            // next interval (nsteps >= 3): the shared counters are stable until the next barrier
+            if (w_s == 1 && w_ord >= 1) {
+                if (MODE == MODE_FILTER) {
+                    const unsigned cnt = lds_w[256];
+                    if (cnt > (unsigned)(CODD_FLUSH_AT)) {
+                        flush_hits(lds_hits, cnt < (unsigned)kHitCap ? cnt : (unsigned)kHitCap, tid, hits, hit_cnt, cap_q, reinterpret_cast<const float*>(lds_w + 320));
+                        __syncthreads();
+                        if (tid == 0) lds_w[256] = 0u;
+                    }
+                } else if (pub_ord == w_ord - 1 && pub_ord < my_tiles) {
+                    if (tid < 256) {
+                        u64 key = lds_k[tid];
+                        if (key) key = make_key(key_score(key) * qscale[tid], key_row(key));  // the fold ran on acc * rscale
+                        bucket_key[(int64_t)tid * ntiles_run + (first_u + (int64_t)pub_ord * G)] = key;
+                        lds_k[tid] = 0ull;
+                    }
+                    ++pub_ord;
+                }
+            }
+            if (++w_s == nsteps) { w_s = 0; w_u += G; ++w_ord; }
+        };
+        if constexpr (LAG == 0 && !CODD_I8_LAG && STEPS3) {
+            // rows whose K-steps are a multiple of the ring length (768 elements: 6): tiles start at ring phase 0, so the
+            // epilogue sits BETWEEN the unrolled intervals and exists once in the program instead of three times (the
+            // inlined copies, each 19 KB of code run once per tile, kept missing the instruction cache)
+            int t = 0;
+            for (int64_t o = 0; o < my_tiles; ++o) {
+                if (pending) {
+                    epilogue(p_u, p_ord);
+                    pending = false;
+                }
+                // the tile's first K-step starts its accumulators from zero: no clearing pass in the epilogue
+                interval(std::integral_constant<int, 0>{}, std::false_type{}, std::true_type{}, t);
+                interval(std::integral_constant<int, 1>{}, std::false_type{}, std::false_type{}, t + 1);
+                interval(std::integral_constant<int, 2>{}, std::false_type{}, std::false_type{}, t + 2);
+                t += 3;
+                for (int s3 = 3; s3 < nsteps; s3 += 3) {
+                    interval(std::integral_constant<int, 0>{}, std::false_type{}, std::false_type{}, t);
+                    interval(std::integral_constant<int, 1>{}, std::false_type{}, std::false_type{}, t + 1);
+                    interval(std::integral_constant<int, 2>{}, std::false_type{}, std::false_type{}, t + 2);
+                    t += 3;
+                }
+            }
+        } else {
+            for (int t0 = 0; t0 < TI; t0 += 3) {
+                interval(std::integral_constant<int, 0>{}, std::true_type{}, std::false_type{}, t0);
+                interval(std::integral_constant<int, 1>{}, std::true_type{}, std::false_type{}, t0 + 1);
+                interval(std::integral_constant<int, 2>{}, std::true_type{}, std::false_type{}, t0 + 2);
+            }
+        }
+        // The corpus loads of the last two intervals are never consumed: hipcc considers their destination registers free
+        // from here on and hands them to the code below, while the loads are still in flight and will overwrite them.
+        // Nothing of this wave may be in flight past this point.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (pending) epilogue(p_u, p_ord);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (MODE == MODE_SAMPLE && pub_ord < my_tiles && tid < 256) {
+            u64 key = lds_k[tid];
+            if (key) key = make_key(key_score(key) * qscale[tid], key_row(key));
+            bucket_key[(int64_t)tid * ntiles_run + (first_u + (int64_t)pub_ord * G)] = key;
+        }
+    };
+    if (CODD_I8_LAG && wave >= 4) run(std::integral_constant<int, CODD_I8_LAG>{});
+    else run(std::integral_constant<int, 0>{});
+
+    if (MODE == MODE_FILTER) {
+        const unsigned cnt = lds_w[256];
+        if (cnt > (unsigned)kHitCap && tid == 0) atomicOr(&flags[FLAG_WG_OVERFLOW], 1u);  // statistics only
+        __syncthreads();  // everyone has read cnt (lds_w[0..255] is about to be reused as the flush's scratch)
+        flush_hits_binned(lds_hits, cnt < (unsigned)kHitCap ? cnt : (unsigned)kHitCap, tid, lds_w, hits, hit_cnt, cap_q, reinterpret_cast<const float*>(lds_w + 320));
+    }
+}
+
+}  // namespace codd

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Build (here) or time (on the GPU box) -D variants of the int8 tile kernel (development tool).
+    python scripts/ab_i8_variants.py build
+    python scripts/ab_i8_variants.py run [rows]
+"""
+import json, os, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+VARIANTS = {
+    "lag1": {"CODD_I8_LAG": 1},
+    "noepi": {"CODD_I8_EXP_NOEPI": 1},
+    "bd3": {"CODD_I8_BDEPTH": 3},
+}
+
+
+def lib(name):
+    return os.path.join(ROOT, "codd_query_engine_amd", "csrc", f"libcodd_knn_{name}.so")
+
+
+if sys.argv[1] == "build":
+    from codd_query_engine_amd import build as b
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(3) as ex:
+        list(ex.map(lambda kv: b.build_variant(kv[0], kv[1]), VARIANTS.items()))
+    print("built", list(VARIANTS))
+else:
+    rows = sys.argv[2] if len(sys.argv) > 2 else "4000000"
+    for name in ["default"] + list(VARIANTS):
+        env = dict(os.environ)
+        if name != "default":
+            if not os.path.exists(lib(name)):
+                continue
+            env["CODD_KNN_LIB"] = lib(name)
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "ab_i8.py"), rows], env=env, capture_output=True, text=True, timeout=280)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        print(name, line[-1] if line else "FAILED " + p.stderr[-300:], flush=True)

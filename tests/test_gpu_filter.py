@@ -198,6 +198,39 @@ def test_dense_cluster_costs_time_not_exactness(Index):
     ix.close()
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_few_valued_rows_do_not_slip_under_the_bf16_bound(Index, dtype):
+    """Rows whose entries all carry the SAME rounding error are the worst case of the bf16 bound: a unit vector of
+    239 equal entries scores 0.99286 against itself in bf16 x bf16 (error 0.0071).  With the unit roundoff taken as
+    2^-9 (round 1) the slack was 0.0040 and such a row — the true top-1 — fell under a threshold anchored on a
+    sampled near-duplicate.  Few-valued vectors are what the hashing embedder produces."""
+    rng = np.random.default_rng(239)
+    n, d, k = 30_000, 768, 10
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    base = np.zeros(d, dtype=np.float32)
+    base[:239] = 1.0
+    members = np.sort(rng.choice(n, size=400, replace=False))
+    for j, r in enumerate(members):
+        row = base.copy()
+        z = j % 20                      # cosine with `base` = sqrt((239 - z) / 239): 1.0 down to 0.959
+        row[rng.choice(239, size=z, replace=False)] = 0.0
+        raw[r] = row
+    two = base.copy()
+    two[:120] = 0.35                   # the embedder's two magnitudes
+    raw[members[-40:]] = two
+    q = rng.standard_normal((24, d)).astype(np.float32)
+    q[0] = base
+    q[1] = two
+    q[2] = base * 3.0
+    q[3, :239] = 1.0
+    ix = build(Index, raw, dtype)
+    dist, rows = ix.search(q, k)
+    assert ix.stat("filter_passes") == 1
+    d_ref, i_ref = oracle_answer(raw, q, k, dtype)
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    ix.close()
+
+
 def test_zero_query_and_zero_rows_through_the_filter(Index):
     """A zero query scores 0 against everything: every row is a candidate and a survivor (20,000 of them, streamed
     through finalize in rounds) and the answer is rows 0..k-1 at distance exactly 1; zero rows score 0 and never

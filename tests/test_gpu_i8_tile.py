@@ -1,0 +1,141 @@
+"""i8_tile_kernel (csrc/filter_i8.h): the int8 filter GEMM of full query blocks (129..256 queries, rows of more than 512
+elements; from 384 elements on with the option i8v2 = 2).  Hand-ordered LDS-DMA staging, a lagging half of the
+workgroup, deferred epilogues with an integer pre-test: all of it may only change SPEED.  Ids and distances must equal
+the oracle's bit for bit, and the candidate lists must be the ones the first-generation kernel writes."""
+
+import numpy as np
+import pytest
+
+from oracle import knn_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def Index():
+    import torch
+
+    assert torch.cuda.is_available()
+    from codd_query_engine_amd.knn_index import DeviceKnnIndex
+
+    return DeviceKnnIndex
+
+
+def build(Index, raw, dtype="f32", i8v2=1):
+    ix = Index(raw.shape[1], dtype=dtype)
+    ix.upsert(np.arange(raw.shape[0], dtype=np.int64), raw)
+    for key in ("filter_min_rows", "filter_min_rows_small", "filter_min_batch"):
+        ix.set_option(key, 1)
+    ix.set_option("shadow8", 1)
+    ix.set_option("i8v2", i8v2)
+    return ix
+
+
+def oracle_answer(raw, q, k, dtype):
+    rows_ref = o.to_storage(o.normalize_rows(raw), dtype)
+    return o.search(rows_ref, dtype, o.normalize_rows(q), k)
+
+
+@pytest.mark.parametrize(
+    "n,d,B,k,dtype,i8v2",
+    [
+        (70_000, 768, 256, 10, "f32", 1),    # the headline shape, scaled down: 274 tiles, 6 K-steps
+        (70_001, 768, 129, 10, "f32", 1),    # ragged last tile, smallest batch that takes this kernel
+        (40_000, 640, 200, 10, "f32", 1),    # 5 K-steps: tiles end at every position of the 3-interval body
+        (40_000, 1024, 256, 10, "f16", 1),   # 8 K-steps (config 5's width)
+        (20_000, 2048, 160, 10, "bf16", 1),  # widest row: 16 K-steps
+        (66_000, 384, 256, 10, "f32", 2),    # 3 K-steps (the smallest this kernel takes), i8v2 = 2
+        (66_000, 512, 255, 100, "f32", 2),   # 4 K-steps, k = 100
+        (6_000, 768, 256, 10, "f32", 1),     # 24 tiles: most workgroups have no tile at all
+        (140_000, 768, 256, 10, "f32", 1),   # 547 tiles: workgroups with 2 and with 3 tiles
+    ],
+)
+def test_tile_kernel_is_exact(Index, n, d, B, k, dtype, i8v2):
+    rng = np.random.default_rng(n + B + d)
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((B, d)).astype(np.float32)
+    q[3] = raw[n // 2] + 0.05 * rng.standard_normal(d).astype(np.float32)  # a query with a real neighbour
+    ix = build(Index, raw, dtype, i8v2)
+    dist, rows = ix.search(q, k)
+    assert ix.stat("i8v2_passes") == 1 and ix.stat("shadow8_passes") == 1
+    d_ref, i_ref = oracle_answer(raw, q, k, dtype)
+    assert np.array_equal(rows, i_ref)
+    assert np.array_equal(dist, d_ref)
+    assert ix.stat("fallback_queries") == 0, "random data must not need the fallback"
+    ix.close()
+
+
+def test_tile_kernel_writes_the_same_candidate_lists_as_the_first_generation(Index):
+    """Same thresholds, same per-row test: the number of candidates and of survivors per pass must not depend on which
+    kernel ran (the integer pre-test may only skip pairs that hold no hit)."""
+    rng = np.random.default_rng(77)
+    n, d, B, k = 120_000, 768, 256, 10
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((B, d)).astype(np.float32)
+    stats = []
+    for v in (0, 1):
+        ix = build(Index, raw, "f32", v)
+        dist, rows = ix.search(q, k)
+        assert ix.stat("i8v2_passes") == v
+        stats.append((ix.stat("filter_hits"), ix.stat("filter_survivors"), dist.copy(), rows.copy()))
+        ix.close()
+    assert stats[0][0] == stats[1][0] and stats[0][1] == stats[1][1]
+    assert np.array_equal(stats[0][2], stats[1][2]) and np.array_equal(stats[0][3], stats[1][3])
+
+
+def test_tile_kernel_negative_and_zero_thresholds_and_zero_queries(Index):
+    """Thresholds <= 0 (queries whose best sampled rows score below the slack), an all-zero query (scale 0: NaN or
+    infinite threshold) and padding queries: the pre-test must hand all of them to the exact per-row test."""
+    rng = np.random.default_rng(5)
+    n, d, B, k = 30_000, 768, 140, 10
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    raw[:, :] *= (rng.random((n, 1)) < 0.5).astype(np.float32) * 0.999 + 0.001  # half of the rows nearly zero before normalisation (same direction: harmless)
+    q = rng.standard_normal((B, d)).astype(np.float32)
+    q[7] = 0.0
+    q[8] = -raw[11]          # best score ~ -1 for row 11, thresholds of this query are low
+    ix = build(Index, raw)
+    dist, rows = ix.search(q, k)
+    assert ix.stat("i8v2_passes") == 1
+    d_ref, i_ref = oracle_answer(raw, q, k, "f32")
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    ix.close()
+
+
+def test_tile_kernel_dense_cluster_overflows_stay_exact(Index):
+    """One tile of near-copies that 160 queries point at: the workgroup's LDS hit list fills inside one tile, the
+    affected queries' counters are poisoned and they are answered by the next stage; everything stays exact."""
+    rng = np.random.default_rng(6)
+    n, d, B, k = 60_000, 768, 200, 10
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    centre = rng.standard_normal(d).astype(np.float32)
+    raw[5120:5376] = centre + 1e-3 * rng.standard_normal((256, d)).astype(np.float32)   # exactly tile 20
+    members = rng.choice(np.arange(6000, n), size=3000, replace=False)
+    raw[members] = centre + 2e-3 * rng.standard_normal((3000, d)).astype(np.float32)    # and a spread-out cluster
+    q = rng.standard_normal((B, d)).astype(np.float32)
+    q[:160] = centre + 1e-3 * rng.standard_normal((160, d)).astype(np.float32)
+    ix = build(Index, raw)
+    dist, rows = ix.search(q, k)
+    assert ix.stat("i8v2_passes") == 1
+    d_ref, i_ref = oracle_answer(raw, q, k, "f32")
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    ix.close()
+
+
+def test_tile_kernel_repeated_searches_and_upserts(Index):
+    """The same index searched repeatedly (stale LDS-DMA state, counters, cooldown logic must not leak between
+    launches), with rows overwritten in between."""
+    rng = np.random.default_rng(8)
+    n, d, B, k = 50_000, 768, 256, 10
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    ix = build(Index, raw)
+    for it in range(4):
+        q = rng.standard_normal((B, d)).astype(np.float32)
+        q[0] = raw[it * 1000 + 5]
+        dist, rows = ix.search(q, k)
+        d_ref, i_ref = oracle_answer(raw, q, k, "f32")
+        assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref), it
+        upd = rng.choice(n, size=500, replace=False)
+        raw[upd] = rng.standard_normal((500, d)).astype(np.float32)
+        ix.upsert(upd.astype(np.int64), raw[upd])
+    assert ix.stat("i8v2_passes") == 4
+    ix.close()
