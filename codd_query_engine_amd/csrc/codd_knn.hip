@@ -665,7 +665,8 @@ struct codd_knn_index : WorkBufs {
     int filter_min_batch = 9;
     int sample_tiles = 4096;  // upper bound on sampled tiles (reached from 42M rows on)
     int sample_div = 40;      // sample about 1/40 of the tiles (2.5 % extra GEMM work), see sample_tile_count()
-    int hit_cap_q = 32768;  // candidates kept per query before it falls back to the exact scan (64 MiB at 256 queries)
+    int hit_cap_q = 131072;  // candidates kept per query before it falls back to the exact scan (256 MiB per searching stream at 256 queries:
+                             // a cluster of 60,000 near-identical rows — closer to each other than either filter's slack — stays on the filter path)
 
     unsigned long long* dstats = nullptr;                  // device counters: hits, survivors, fallback queries
 
@@ -707,6 +708,7 @@ struct codd_knn_index : WorkBufs {
     int shadow8_cooldown = 256;
     int cooldown_left = 0;
     int64_t stat_cooldowns = 0;
+    int64_t cooldown_useless_epoch = -1;  // row epoch at which the bf16 filter was seen to leave as many survivors as the int8 one: no more cooldowns until rows change
     float exp_slack_scale = 1.0f;  // diagnostic only ("exp_slack_pct"): < 1 makes the int8 filter UNSOUND; what-if timing
 
     // IVF (optional): rows regrouped by coarse list, original slots, list offsets, the coarse index
@@ -1433,9 +1435,18 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
             const unsigned long long surv = ix->watch_host[1], fb = ix->watch_host[2];
             if (ix->watch_q8_sent > 0 && ix->watch_q16_sent == 0) {  // only int8 passes in the window: the deltas are theirs
                 const double per_q = (double)(surv - ix->watch_surv) / (double)ix->watch_q8_sent;
-                if (per_q > (double)ix->shadow8_max_surv || (fb - ix->watch_fb) * 20 > (unsigned long long)ix->watch_q8_sent) {
+                if ((per_q > (double)ix->shadow8_max_surv || (fb - ix->watch_fb) * 20 > (unsigned long long)ix->watch_q8_sent) &&
+                    ix->cooldown_useless_epoch != ix->epoch) {
                     ix->cooldown_left = ix->shadow8_cooldown;
                     ix->stat_cooldowns++;
+                }
+            } else if (ix->watch_q16_sent > 0 && ix->watch_q8_sent == 0) {
+                // only bf16 passes (a cooldown): when those leave the re-scoring just as crowded — rows closer to each other than
+                // EITHER slack — the slower bf16 kernel buys nothing: stay on int8 until rows change
+                const double per_q = (double)(surv - ix->watch_surv) / (double)ix->watch_q16_sent;
+                if (per_q > (double)ix->shadow8_max_surv) {
+                    ix->cooldown_useless_epoch = ix->epoch;
+                    ix->cooldown_left = 0;
                 }
             }
             ix->watch_surv = surv;

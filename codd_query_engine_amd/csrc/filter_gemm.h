@@ -532,14 +532,15 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
                                         lds_hits[slot * 3 + 1] = (unsigned)row;
                                         lds_hits[slot * 3 + 2] = (unsigned)(qbase + qb * kMB);
                                     } else {
-                                        // workgroup list full (> kHitCap/2 hits inside ONE tile: a dense cluster
-                                        // that many queries point at): this query's candidates are incomplete ->
-                                        // poison its counter (top bit: reads as "> cap", can never wrap) so that
-                                        // finalize queues exactly this query for the exact scan.  (Appending to the
-                                        // global list from here instead was measured 5 % slower on the whole kernel:
-                                        // the extra address arithmetic / call in the epilogue hurts the MFMA loop's
-                                        // register allocation.)
-                                        atomicOr(&hit_cnt[(qbase + qb * kMB) * kHitCntStride], 0x80000000u);
+                                        // workgroup list full (> kHitCap/2 hits inside ONE tile: a dense cluster that many
+                                        // queries point at): straight to the query's global list — slow (a returning global
+                                        // atomic per hit) but complete, so the query needs no exact-scan fallback.  (Round 1
+                                        // poisoned the query's counter here instead and sent it to the fallback: 168 ms per
+                                        // batch on a corpus of 64 tight clusters.)
+                                        unsigned gq = (unsigned)(qbase + qb * kMB);
+                                        asm volatile("" : "+v"(gq));  // (opaque: hipcc otherwise hoists these addresses out of the K loop and spills them)
+                                        const unsigned gslot = atomicAdd(&hit_cnt[gq * kHitCntStride], 1u);
+                                        if (gslot < (unsigned)cap_q) hits[(int64_t)gq * cap_q + gslot] = make_key(EL ? v * qscale[gq] : v, (uint32_t)row);
                                     }
                                 }
                             }

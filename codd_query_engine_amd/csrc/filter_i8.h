@@ -25,7 +25,7 @@
 //     conditional region;
 //   * the workgroup's hit-list bookkeeping rides on the interval barrier: no extra barriers per tile.
 //
-// LDS: 4 query slices x 32 KiB | 832 bookkeeping words | 4 row-scale buffers x (256 + 16) floats | hit list.
+// LDS: 4 query slices x 32 KiB | 1088 bookkeeping words | 2 row-scale buffers x (256 + 16) floats | hit list.
 #pragma once
 #include "filter_gemm.h"
 
@@ -36,7 +36,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kI8SliceBytes = 32768;  // one 128-wide K slice of the 256-query block
-constexpr int kI8RsBufs = 4;          // row-scale buffers (tile ordinal & 3)
+constexpr int kI8RsBufs = 2;          // row-scale buffers (tile ordinal & 1): a tile's scales are read (its epilogue, at the start of the next tile) before the tile after next requests its own
 constexpr int kI8RsStride = 272;      // floats per buffer: 256 row scales + 8 per-wave maxima (+ pad)
 #ifndef CODD_I8_BDEPTH
 #define CODD_I8_BDEPTH 4              // query-fragment register sets in flight
@@ -93,8 +93,9 @@ __device__ __forceinline__ void lgkm_wait_asm(i32x4& v) {
 // vector-memory operations per interval, in issue order: scale DMA, kDmaPerIv slice DMA, kAPerIv corpus loads
 constexpr int kDmaPerIv = 4, kAPerIv = 4, kOpsPerIv = 1 + kDmaPerIv + kAPerIv;
 // bookkeeping words behind the slices: [0..255] pre-test thresholds, transposed ([query & 15][query >> 4]); [256] hit count;
-// [320..575] query scales; [576..831] exact thresholds (thr / qscale), by query.  SAMPLE: [0..511] = 256 u64 keys.
-constexpr int kI8Words = 832;
+// [320..575] query scales; [576..831] exact thresholds (thr / qscale), by query; [832..1087] scratch of the in-loop flush.
+// SAMPLE: [0..511] = 256 u64 keys.
+constexpr int kI8Words = 1088;
 
 __host__ __device__ constexpr size_t i8_lds_bytes(int mode) {
     return (size_t)4 * kI8SliceBytes + kI8Words * 4 + kI8RsBufs * kI8RsStride * 4 + (mode == MODE_FILTER ? (size_t)kHitCap * 12 : 0);
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         q_s = q_s + 1 == nsteps ? 0 : q_s + 1;
     };
 
-    // ---- row scales of run-tile ordinal u (this workgroup's tile number `ord`) -> LDS buffer ord & 3, by DMA too ----
+    // ---- row scales of run-tile ordinal u (this workgroup's tile number `ord`) -> LDS buffer ord & 1, by DMA too ----
     // one 256-byte DMA per wave and interval: the scales of rows [r0, r0 + 64) of the tile, r0 = min(32 wave, 192) — the
     // wave's own 32 rows among them (neighbouring waves write the same bytes twice).  Every interval of a tile repeats
     // the request (same bytes): the number of operations per interval stays fixed, which the counted waits rely on.
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         const int64_t left = bound - row0;
         const int rows_here = left >= kTileRows ? kTileRows : (left > 0 ? (int)left : 0);
         const int r0 = wave * 32 < 192 ? wave * 32 : 192;
-        i8_dma_b32(lds0 + (unsigned)(4 * kI8SliceBytes + kI8Words * 4 + ((ord & 3) * kI8RsStride + r0) * 4), lane4,
+        i8_dma_b32(lds0 + (unsigned)(4 * kI8SliceBytes + kI8Words * 4 + ((ord & 1) * kI8RsStride + r0) * 4), lane4,
                    i8_rsrc(rscale + (left > 0 ? row0 : 0), (unsigned)(rows_here * 4)), r0 * 4);
     };
 
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         int c = lane & 15, lg = lane >> 4;
         asm volatile("" : "+v"(c), "+v"(lg));
         const int64_t tile = cu * tile_stride;
-        const float* rsb = lds_rs + (ord & 3) * kI8RsStride;
+        const float* rsb = lds_rs + (ord & 1) * kI8RsStride;
         const unsigned row0 = (unsigned)(tile * kTileRows) + (unsigned)(wave * 32 + 4 * lg);  // + 16 * rs + r
         const f32x4 rsc0 = *reinterpret_cast<const f32x4*>(rsb + wave * 32 + 4 * lg);
         const f32x4 rsc1 = *reinterpret_cast<const f32x4*>(rsb + wave * 32 + 16 + 4 * lg);
@@ -251,9 +252,12 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                                     lds_hits[slot * 3 + 1] = row0 + (unsigned)(16 * (i >> 2) + (i & 3));
                                     lds_hits[slot * 3 + 2] = q;
                                 } else {
-                                    // workgroup list full (a dense cluster many queries point at): this query's candidates
-                                    // are incomplete -> poison its counter, finalize sends exactly this query to the next stage
-                                    atomicOr(&hit_cnt[q * kHitCntStride], 0x80000000u);
+                                    // workgroup list full (a dense cluster many queries point at, more hits inside one tile
+                                    // than the list holds): straight to the query's global list.  Slow (a returning global
+                                    // atomic per hit) but complete: the query keeps its candidates and needs no fallback.
+                                    const unsigned gslot = atomicAdd(&hit_cnt[q * kHitCntStride], 1u);
+                                    if (gslot < (unsigned)cap_q)
+                                        hits[(int64_t)q * cap_q + gslot] = make_key(v[i] * __uint_as_float(lds_w[320 + q]), row0 + (unsigned)(16 * (i >> 2) + (i & 3)));
                                 }
                             }
                         }
@@ -381,7 +385,9 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                 if (MODE == MODE_FILTER) {
                     const unsigned cnt = lds_w[256];
                     if (cnt > (unsigned)(CODD_FLUSH_AT)) {
-                        flush_hits(lds_hits, cnt < (unsigned)kHitCap ? cnt : (unsigned)kHitCap, tid, hits, hit_cnt, cap_q, reinterpret_cast<const float*>(lds_w + 320));
+                        // (per-query ranges reserved with one global atomic each: on clustered corpora a tile fills the list
+                        // and every workgroup flushes every tile; one atomic per hit serialises on 256 counters)
+                        flush_hits_binned(lds_hits, cnt < (unsigned)kHitCap ? cnt : (unsigned)kHitCap, tid, lds_w + 832, hits, hit_cnt, cap_q, reinterpret_cast<const float*>(lds_w + 320));
                         __syncthreads();
                         if (tid == 0) lds_w[256] = 0u;
                     }

@@ -289,6 +289,14 @@ class MetricsSemanticIndexerJob:
         """Per metric: dry-run display | skip when present | enrich + index; a failure of one metric
         never stops the batch (reference job.py:359-461)."""
         print(f"      Batch {batch_num}/{total_batches} ({len(batch)} metrics):")
+        # Batched ingest: a store that offers the two-phase API (this build's MetricsSemanticMetadataStore) validates and
+        # composes every metric where the reference indexes it — same exceptions, same place in the report — and the
+        # batch goes to the device in ONE upsert at the end.  Any other store (the reference's interface: one
+        # index_metadata call per metric) is driven exactly as the reference drives it.
+        prepare = getattr(self.semantic_store, "prepare_index", None)
+        commit = getattr(self.semantic_store, "commit_index", None)
+        two_phase = callable(prepare) and callable(commit)
+        prepared: list = []
         for item in batch:
             name = item["metric"]
             mtype = item.get("type", "unknown")
@@ -309,7 +317,10 @@ class MetricsSemanticIndexerJob:
                     metric_name=name, metric_type=mtype, description=help_text if help_text else None
                 )
                 self.stats.enriched_metrics += 1
-                self.semantic_store.index_metadata(namespace, enriched)
+                if two_phase:
+                    prepared.append(prepare(namespace, enriched))
+                else:
+                    self.semantic_store.index_metadata(namespace, enriched)
                 self.stats.indexed_metrics += 1
                 print(
                     f" ✓ (category: {enriched.get('category', 'N/A')}, "
@@ -324,7 +335,26 @@ class MetricsSemanticIndexerJob:
                 else:
                     print(f" ✗ (error: {str(exc)[:50]}...)")
                     logger.error(f"Failed to process metric: {name}", exc_info=True)
+        if prepared:
+            self._commit_batch(prepared, commit)
         print()
+
+    def _commit_batch(self, prepared: list, commit: Callable[[list], Any]) -> None:
+        """One upsert for the batch.  If the store rejects it as a whole (a device error, not a validation error: those
+        were raised per metric above), the metrics are retried one by one so that the counters name the ones that failed."""
+        try:
+            commit(prepared)
+            return
+        except Exception as exc:
+            logger.error(f"Batched upsert of {len(prepared)} metrics failed ({exc}); retrying one by one")
+        for one in prepared:
+            try:
+                commit([one])
+            except Exception as exc:
+                self.stats.indexed_metrics -= 1
+                self.stats.failed_metrics += 1
+                print(f"        ✗ {one[0]} (error: {str(exc)[:50]}...)")
+                logger.error(f"Failed to index metric: {one[0]}", exc_info=True)
 
     def _print_summary(self) -> None:
         s = self.stats

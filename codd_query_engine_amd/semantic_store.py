@@ -167,6 +167,25 @@ class MetricsSemanticMetadataStore:
         logger.debug(f"Indexed metric: {document_id}")
         return document_id
 
+    # Two-phase ingest for the indexer job (SURVEY.md §8f1 "batched upsert"; the reference upserts one row per call,
+    # store.py:236): `prepare_index` does everything index_metadata does up to the upsert — same KeyError /
+    # ValidationError at the same point for a bad record — and `commit_index` sends a whole batch in ONE upsert
+    # (one embedding call, one ingest launch on the device).
+    def prepare_index(self, namespace: str, metadata: MetricMetadata) -> tuple:
+        return self._compose(namespace, metadata)
+
+    def commit_index(self, prepared: list) -> list[str]:
+        if not prepared:
+            return []
+        ids = [p[0] for p in prepared]
+        try:
+            self.collection.upsert(documents=[p[1] for p in prepared], metadatas=[p[2] for p in prepared], ids=ids)
+        except Exception as exc:
+            logger.error(f"Failed to index {len(ids)} metrics ('{ids[0]}' ...): {exc}")
+            raise
+        logger.debug(f"Indexed {len(ids)} metrics in one upsert")
+        return ids
+
     def index_metadata_batch(self, namespace: str, records: Iterable[MetricMetadata]) -> list[str]:
         """Extension: validate every record first, then ONE upsert (one ingest launch)."""
         composed = [self._compose(namespace, r) for r in records]

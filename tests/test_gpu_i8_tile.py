@@ -139,3 +139,27 @@ def test_tile_kernel_repeated_searches_and_upserts(Index):
         ix.upsert(upd.astype(np.int64), raw[upd])
     assert ix.stat("i8v2_passes") == 4
     ix.close()
+
+
+def test_forty_thousand_near_copies_stay_on_the_filter_path(Index):
+    """The dense-cluster cliff of round 1: more near-identical rows than a query's candidate list held sent every query to
+    32 sequential exact scans (168 ms instead of 2.7).  42,000 rows closer to each other than the int8 slack, 200 of 256
+    queries pointing at them: the workgroup lists overflow inside every tile (direct global appends), every affected
+    query collects 42,000 candidates, finalize re-scores them all — exact, and without the exact-scan fallback."""
+    rng = np.random.default_rng(40)
+    n, d, B, k = 60_000, 768, 256, 10
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    centre = rng.standard_normal(d).astype(np.float32)
+    centre /= np.linalg.norm(centre)
+    members = rng.choice(n, size=42_000, replace=False)
+    raw[members] = centre + 0.1 * rng.standard_normal((42_000, d)).astype(np.float32) / np.sqrt(d)
+    q = rng.standard_normal((B, d)).astype(np.float32)
+    q[:200] = centre + 0.1 * rng.standard_normal((200, d)).astype(np.float32) / np.sqrt(d)
+    ix = build(Index, raw)
+    dist, rows = ix.search(q, k)
+    assert ix.stat("i8v2_passes") == 1
+    d_ref, i_ref = oracle_answer(raw, q, k, "f32")
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    assert ix.stat("fallback_queries") == 0
+    assert ix.stat("filter_survivors") >= 200 * 40_000
+    ix.close()

@@ -140,3 +140,26 @@ def test_job_end_to_end_on_the_hip_engine():
     assert job.stats.indexed_metrics == 4 and job.stats.excluded_metrics == 1
     hits = job.semantic_store.search_metadata("failed database queries", n_results=1)
     assert hits[0]["metric_name"] == "db_query_errors_total"
+
+
+def test_real_store_is_fed_one_upsert_per_batch():
+    """the reference upserts one row per call (store.py:236); this job validates per metric and sends each
+    batch to the engine in ONE upsert.  Validation failures still surface per metric, at the same place in the report."""
+    upserts = []
+
+    class CountingEngine(OracleEngine):
+        def upsert(self, slots, vecs, normalize=True):
+            upserts.append(len(slots))
+            return super().upsert(slots, vecs, normalize)
+
+    prom = dict(PROM)
+    prom["bad name!"] = [{"type": "gauge", "help": "fails store validation"}]
+    client = KnnClient(engine_factory=lambda dim: CountingEngine(dim))
+    job = MetricsSemanticIndexerJob(None, client, None, None, None, batch_size=4, metadata_source=lambda cfg: StaticMetadataSource(prom))
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        job.run("prod:api")
+    assert upserts == [4, 1], upserts           # 6 metrics in batches of 4 + 2; the bad name never reaches the engine
+    assert job.stats.indexed_metrics == 5 and job.stats.failed_metrics == 1 and job.stats.enriched_metrics == 6
+    assert "→ Enriching: bad name! ✗ (error: metric_name contains invalid characters" in out.getvalue()
+    assert job.semantic_store.collection.count() == 5
