@@ -26,6 +26,10 @@
 #include <vector>
 
 #include "codd_knn.h"
+
+#ifndef CODD_EXPERIMENTS
+#define CODD_EXPERIMENTS 0  // 1 (build_variant only): the diagnostic switches that can return wrong results exist
+#endif
 #include "filter_gemm.h"
 #include "filter_i8.h"
 #include "row_traits.h"
@@ -342,6 +346,13 @@ __global__ __launch_bounds__(256) void merge_keys_kernel(const u64* __restrict__
 // ivf_scan_kernel   : block (x, b) scans slice x%split of the list that query b probes at rank x/split,
 //                     canonical exact scores, per-wave top-k, keys carry the ORIGINAL row slot.
 // ---------------------------------------------------------------------------------------------
+// perm_check_kernel: sets *bad when any perm[i] lies outside [0, n) (codd_knn_ivf_install trusts no caller-built table:
+// gather_rows_kernel and ivf_scan_kernel index rows with these values)
+__global__ __launch_bounds__(256) void perm_check_kernel(const int64_t* __restrict__ perm, int64_t n, unsigned* __restrict__ bad) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n && (perm[i] < 0 || perm[i] >= n)) atomicOr(bad, 1u);
+}
+
 __global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restrict__ src, const int64_t* __restrict__ perm, int64_t n,
                                                           int chunks_per_row, uint4* __restrict__ dst, uint32_t* __restrict__ ids) {
     const int lane = lane_id();
@@ -493,6 +504,33 @@ __global__ __launch_bounds__(256) void prep_queries8_kernel(const float* __restr
         const float eq = __builtin_sqrtf(err2) * 1.0001f + 1e-7f, er = __uint_as_float(*eps_r_bits);
         qmeta[q] = scale;
         qmeta[256 + q] = slack_scale * 2.0f * (eq * (1.01f + er) + 1.001f * er + 2e-6f);
+    }
+}
+
+// row_norm_check_kernel: largest | |c| - 1 | over stored rows [first, first + n) that are not all-zero, folded into *dev_bits
+// (non-negative floats order as their bits).  codd_knn_load_rows trusts nothing it is handed: both filters' bounds assume unit
+// rows, and rows written with normalize = 0 (or a damaged rows.bin) must switch them off, not return wrong neighbours.
+template <int DT>
+__global__ __launch_bounds__(256) void row_norm_check_kernel(const void* __restrict__ rows_, int64_t first, int64_t n, int dpad,
+                                                             unsigned* __restrict__ dev_bits) {
+    typedef RowTraits<DT> RT;
+    constexpr int E = RT::E;
+    const int lane = lane_id();
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int nchunks = dpad / E;
+    const uint4* p = reinterpret_cast<const uint4*>(rows_) + (first + r) * (int64_t)nchunks;
+    float acc = 0.0f;
+    for (int j = lane; j < nchunks; j += kWave) {
+        float w[E];
+        RT::widen(p[j], w);
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc = __builtin_fmaf(w[e], w[e], acc);
+    }
+    const float nrm = __builtin_sqrtf(butterfly_sum(acc));
+    if (lane == 0 && nrm != 0.0f) {
+        const float dev = nrm == nrm ? fabsf(nrm - 1.0f) : INFINITY;  // NaN rows count as infinitely far from unit
+        atomicMax(dev_bits, __float_as_uint(dev));
     }
 }
 
@@ -654,8 +692,23 @@ struct codd_knn_index : WorkBufs {
     int64_t capacity = 0;  // row slots allocated
     int64_t count = 0;     // highest written slot + 1
     void* rows = nullptr;  // [capacity][dpad] storage dtype
-    uint4* shadow = nullptr;       // bf16 fragment-order copy, whole 256-row tiles
+    // bf16 fragment-order copy, whole 256-row tiles.  Derived data like the int8 shadow: built lazily from the stored rows by the
+    // first search that needs it (batches above 256 queries, an index with the int8 filter off or cooling down, the IVF
+    // build), brought up to date incrementally over the rows written since
+    uint4* shadow = nullptr;
     int64_t shadow_rows = 0;       // rows the shadow allocation covers (multiple of 256)
+    int64_t shadow_epoch = -1;
+    int64_t dirty16_lo = 0, dirty16_hi = 0;
+    hipStream_t shadow_stream = nullptr;
+    hipEvent_t shadow_ready = nullptr;
+    int64_t stat_shadow_builds = 0;
+    // stored rows written on a caller's stream (upsert_device): searches on other streams wait for this on the device
+    hipEvent_t rows_ready = nullptr;
+    hipStream_t rows_stream = nullptr;
+    bool rows_event_set = false;
+    // staging of codd_knn_upsert_host (kept between calls: the indexer job upserts in small batches)
+    float* stage_vec = nullptr;   int64_t stage_vec_cap = 0;
+    int64_t* stage_slot = nullptr; int64_t stage_slot_cap = 0;
     bool all_normalized = true;    // false once a caller stored rows with normalize = 0
 
     // filter path knobs
@@ -709,7 +762,7 @@ struct codd_knn_index : WorkBufs {
     int cooldown_left = 0;
     int64_t stat_cooldowns = 0;
     int64_t cooldown_useless_epoch = -1;  // row epoch at which the bf16 filter was seen to leave as many survivors as the int8 one: no more cooldowns until rows change
-    float exp_slack_scale = 1.0f;  // diagnostic only ("exp_slack_pct"): < 1 makes the int8 filter UNSOUND; what-if timing
+    float exp_slack_scale = 1.0f;  // always 1 in the shipped library; "exp_slack_pct" exists only in -DCODD_EXPERIMENTS=1 builds
 
     // IVF (optional): rows regrouped by coarse list, original slots, list offsets, the coarse index
     codd_knn_index* coarse = nullptr;  // nlist centroids, f32
@@ -751,6 +804,11 @@ void rows_written(codd_knn_index* ix, int64_t lo, int64_t hi) {
     else {
         if (lo < ix->dirty_lo) ix->dirty_lo = lo;
         if (hi > ix->dirty_hi) ix->dirty_hi = hi;
+    }
+    if (ix->dirty16_hi <= ix->dirty16_lo) { ix->dirty16_lo = lo; ix->dirty16_hi = hi; }
+    else {
+        if (lo < ix->dirty16_lo) ix->dirty16_lo = lo;
+        if (hi > ix->dirty16_hi) ix->dirty16_hi = hi;
     }
 }
 
@@ -836,7 +894,8 @@ struct WorkScope {
 size_t elem_size(int dtype) { return dtype == DT_F32 ? 4 : 2; }
 int elems_per_chunk(int dtype) { return dtype == DT_F32 ? 4 : 8; }
 
-// (re)allocate row storage + shadow for at least `need` slots, preserving contents
+// (re)allocate row storage for at least `need` slots, preserving contents (the shadows are derived data with their own
+// allocations: ensure_shadow / ensure_shadow8)
 int grow_rows(codd_knn_index* ix, int64_t need, bool exact) {
     if (need <= ix->capacity) return CODD_KNN_OK;
     int64_t cap = need;
@@ -845,34 +904,17 @@ int grow_rows(codd_knn_index* ix, int64_t need, bool exact) {
         while (cap < need) cap += cap / 2 + 1024;
     }
     const size_t row_bytes = (size_t)ix->dpad * elem_size(ix->dtype);
-    const int64_t srows = (cap + kTileRows - 1) / kTileRows * kTileRows;
-    const size_t shadow_bytes = (size_t)srows * ix->dpad * 2;
     void* fresh = nullptr;
-    uint4* fresh_shadow = nullptr;
     HIP_TRY(hipMalloc(&fresh, (size_t)cap * row_bytes));
-    if (hipMalloc((void**)&fresh_shadow, shadow_bytes) != hipSuccess) {
-        (void)hipFree(fresh);
-        return fail(CODD_KNN_ENOMEM, "shadow allocation failed%s");
-    }
     hipError_t e = hipMemset(fresh, 0, (size_t)cap * row_bytes);
-    if (e == hipSuccess) e = hipMemset(fresh_shadow, 0, shadow_bytes);
-    if (e == hipSuccess && ix->rows && ix->count > 0) {
-        e = hipMemcpy(fresh, ix->rows, (size_t)ix->count * row_bytes, hipMemcpyDeviceToDevice);
-        // the shadow is block-major (32-row blocks are contiguous): copy the blocks in use
-        const int64_t blocks = (ix->count + 31) / 32;
-        if (e == hipSuccess) e = hipMemcpy(fresh_shadow, ix->shadow, (size_t)blocks * 32 * ix->dpad * 2, hipMemcpyDeviceToDevice);
-    }
+    if (e == hipSuccess && ix->rows && ix->count > 0) e = hipMemcpy(fresh, ix->rows, (size_t)ix->count * row_bytes, hipMemcpyDeviceToDevice);
     if (e != hipSuccess) {
         (void)hipFree(fresh);
-        (void)hipFree(fresh_shadow);
         return fail(CODD_KNN_EDEVICE, "row copy on growth failed: %s", hipGetErrorString(e));
     }
     if (ix->rows) (void)hipFree(ix->rows);
-    if (ix->shadow) (void)hipFree(ix->shadow);
     ix->rows = fresh;
-    ix->shadow = fresh_shadow;
     ix->capacity = cap;
-    ix->shadow_rows = srows;
     return CODD_KNN_OK;
 }
 
@@ -1131,6 +1173,54 @@ int64_t sample_tile_count(const codd_knn_index* ix, int64_t ntiles, int k, bool 
 }
 
 int dpad8_of(const codd_knn_index* ix) { return (ix->dpad + 127) / 128 * 128; }
+
+// Searches on a stream other than the one rows were last written on (codd_knn_upsert_device is asynchronous on the caller's
+// stream) wait for that write on the device before they read rows or rebuild a shadow from them.
+int wait_rows(codd_knn_index* ix, hipStream_t st) {
+    if (ix->rows_event_set && st != ix->rows_stream) HIP_TRY(hipStreamWaitEvent(st, ix->rows_ready, 0));
+    return CODD_KNN_OK;
+}
+
+// The bf16 shadow, like the int8 one, is derived data: (re)built from the stored rows on the searching stream whenever rows
+// have been written since the last build, over the dirty row range only.  An index that only ever sees batches of <= 256
+// queries (the int8 filter) never allocates it: 38 GB instead of 54 GB for the 10M x 768 fp32 corpus.
+int ensure_shadow(codd_knn_index* ix, hipStream_t st) {
+    const int64_t n = ix->count;
+    if (ix->shadow_epoch == ix->epoch && ix->shadow) {
+        if (st != ix->shadow_stream && ix->shadow_ready) HIP_TRY(hipStreamWaitEvent(st, ix->shadow_ready, 0));
+        return CODD_KNN_OK;
+    }
+    const int64_t need = (n + kTileRows - 1) / kTileRows * kTileRows;
+    int64_t first = ix->dirty16_lo, m = ix->dirty16_hi - ix->dirty16_lo;
+    if (need > ix->shadow_rows) {
+        HIP_TRY(hipDeviceSynchronize());  // every stream that may still read the old allocation is done with it
+        if (ix->shadow) (void)hipFree(ix->shadow);
+        ix->shadow = nullptr; ix->shadow_rows = 0;
+        const int64_t rows = need + need / 8;
+        const int64_t rows_al = (rows + kTileRows - 1) / kTileRows * kTileRows;
+        HIP_TRY(hipMalloc((void**)&ix->shadow, (size_t)rows_al * ix->dpad * 2));
+        ix->shadow_rows = rows_al;
+        HIP_TRY(hipMemsetAsync(ix->shadow, 0, (size_t)rows_al * ix->dpad * 2, st));  // rows beyond the count are masked, their bytes only have to be defined
+        first = 0; m = n;
+    }
+    if (!ix->shadow_ready) HIP_TRY(hipEventCreateWithFlags(&ix->shadow_ready, hipEventDisableTiming));
+    if (m > 0) {
+        const dim3 grid((unsigned)((m + 3) / 4)), block(256);
+        uint2* sh = reinterpret_cast<uint2*>(ix->shadow);
+        switch (ix->dtype) {
+            case DT_F32: hipLaunchKernelGGL(shadow_from_rows_kernel<DT_F32>, grid, block, 0, st, ix->rows, first, m, ix->dpad, sh); break;
+            case DT_BF16: hipLaunchKernelGGL(shadow_from_rows_kernel<DT_BF16>, grid, block, 0, st, ix->rows, first, m, ix->dpad, sh); break;
+            default: hipLaunchKernelGGL(shadow_from_rows_kernel<DT_F16>, grid, block, 0, st, ix->rows, first, m, ix->dpad, sh); break;
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(ix->shadow_ready, st));
+    ix->shadow_stream = st;
+    ix->shadow_epoch = ix->epoch;
+    ix->dirty16_lo = ix->dirty16_hi = 0;
+    ix->stat_shadow_builds++;
+    return CODD_KNN_OK;
+}
 
 // The int8 shadow is derived data: (re)built from the stored rows on the searching stream whenever rows have been
 // written since the last build.  Other streams that search before the build has finished wait for it on the device.
@@ -1403,7 +1493,7 @@ bool filter_applies(const codd_knn_index* ix, int B, int k) {
     // the thresholds come from the k-th largest of the sampled tile maxima: need comfortably more tiles than k
     const int64_t ntiles = (ix->count + kTileRows - 1) / kTileRows;
     const int64_t ts = sample_tile_count(ix, ntiles, k);
-    if (!(ix->filter_enabled && ix->all_normalized && ix->shadow) || ts < 2 * (int64_t)k) return false;
+    if (!(ix->filter_enabled && ix->all_normalized) || ts < 2 * (int64_t)k) return false;
     // measured on MI355X (scripts/crossover.py, d = 768): with more than 8 queries the filter wins at every size
     // it is sound for; up to 8 queries the exact scan's single launch wins until rows * B reaches ~100k
     if (B >= ix->filter_min_batch) return ix->count >= ix->filter_min_rows;
@@ -1423,6 +1513,7 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
     int rc;
     if ((rc = ensure_buf(&ix->qn, &ix->qn_cap, (int64_t)B * ix->dpad)) != 0) return rc;
     if ((rc = ensure_buf(&ix->keys_tmp, &ix->keys_tmp_cap, (int64_t)B * k)) != 0) return rc;
+    if ((rc = wait_rows(ix, st)) != 0) return rc;
     const bool use_filter = n > 0 && filter_applies(ix, B, k);
     const bool fused_prep = use_filter && B <= kTileQ;
     if (ix->eps_r_copied) {
@@ -1477,6 +1568,7 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
         if (!ix->qmeta) HIP_TRY(hipMalloc((void**)&ix->qmeta, 512 * sizeof(float)));
     } else if (fused_prep) {
         if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
+        if ((rc = ensure_shadow(ix, st)) != 0) return rc;
         hipLaunchKernelGGL(prep_queries_kernel, dim3(kTileQ / 4), dim3(256), 0, st, dev_queries, B, ix->dim, ix->dpad, ix->qn,
                            reinterpret_cast<uint2*>(ix->qfrag), reinterpret_cast<unsigned*>(ix->ctl), (int)(sizeof(FilterCtl) / 4));
         HIP_TRY(hipGetLastError());
@@ -1493,6 +1585,7 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
         HIP_TRY(hipMemsetAsync(keys_dst, 0, (size_t)B * k * sizeof(u64), st));
     } else if (use_filter) {
         if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
+        if (!use8 && (rc = ensure_shadow(ix, st)) != 0) return rc;
         for (int q0 = 0; q0 < B; q0 += kTileQ) {
             const int nq = B - q0 < kTileQ ? B - q0 : kTileQ;
             if (use8 && (rc = prep8(q0, nq)) != 0) return rc;
@@ -1570,6 +1663,10 @@ int codd_knn_destroy(codd_knn_index* ix) {
     (void)hipDeviceSynchronize();
     void* bufs[] = {ix->rows, ix->shadow, ix->dstats, ix->rows_ivf, ix->ivf_ids, ix->ivf_offsets, ix->shadow8, ix->rscale, ix->eps_r_bits};
     if (ix->shadow8_ready) (void)hipEventDestroy(ix->shadow8_ready);
+    if (ix->shadow_ready) (void)hipEventDestroy(ix->shadow_ready);
+    if (ix->rows_ready) (void)hipEventDestroy(ix->rows_ready);
+    if (ix->stage_vec) (void)hipFree(ix->stage_vec);
+    if (ix->stage_slot) (void)hipFree(ix->stage_slot);
     if (ix->watch_copied) (void)hipEventDestroy(ix->watch_copied);
     if (ix->watch_host) (void)hipHostFree(ix->watch_host);
     if (ix->eps_r_copied) (void)hipEventDestroy(ix->eps_r_copied);
@@ -1611,16 +1708,26 @@ int codd_knn_upsert_host(codd_knn_index* ix, const int64_t* host_slots, const fl
     HIP_TRY(hipDeviceSynchronize());
     int rc = grow_rows(ix, max_slot + 1, /*exact=*/false);
     if (rc != 0) return rc;
-    // stage in bounded pieces (<= 64 MiB of vectors per piece)
+    // stage in bounded pieces (<= 64 MiB of vectors per piece) through buffers the index keeps between calls (the indexer job
+    // upserts one small batch at a time: a hipMalloc / hipFree pair per call used to dominate them)
     const int64_t piece = (int64_t)(64ll << 20) / ((int64_t)ix->dim * 4) + 1;
-    float* dvec = nullptr;
-    int64_t* dslot = nullptr;
     const int64_t pn = n < piece ? n : piece;
-    HIP_TRY(hipMalloc((void**)&dvec, (size_t)pn * ix->dim * sizeof(float)));
-    if (hipMalloc((void**)&dslot, (size_t)pn * sizeof(int64_t)) != hipSuccess) {
-        (void)hipFree(dvec);
-        return fail(CODD_KNN_ENOMEM, "staging allocation failed%s");
+    if (pn * ix->dim > ix->stage_vec_cap) {
+        if (ix->stage_vec) (void)hipFree(ix->stage_vec);
+        ix->stage_vec = nullptr; ix->stage_vec_cap = 0;
+        const int64_t want = pn * ix->dim < 65536 ? 65536 : pn * ix->dim;
+        HIP_TRY(hipMalloc((void**)&ix->stage_vec, (size_t)want * sizeof(float)));
+        ix->stage_vec_cap = want;
     }
+    if (pn > ix->stage_slot_cap) {
+        if (ix->stage_slot) (void)hipFree(ix->stage_slot);
+        ix->stage_slot = nullptr; ix->stage_slot_cap = 0;
+        const int64_t want = pn < 4096 ? 4096 : pn;
+        HIP_TRY(hipMalloc((void**)&ix->stage_slot, (size_t)want * sizeof(int64_t)));
+        ix->stage_slot_cap = want;
+    }
+    float* dvec = ix->stage_vec;
+    int64_t* dslot = ix->stage_slot;
     rc = CODD_KNN_OK;
     for (int64_t i0 = 0; i0 < n && rc == 0; i0 += pn) {
         const int64_t m = n - i0 < pn ? n - i0 : pn;
@@ -1630,11 +1737,11 @@ int codd_knn_upsert_host(codd_knn_index* ix, const int64_t* host_slots, const fl
             rc = fail(CODD_KNN_EDEVICE, "staging copy failed: %s", hipGetErrorString(e));
             break;
         }
-        rc = launch_normalize(ix->dtype, dvec, m, ix->dim, ix->dpad, normalize, dslot, 0, ix->rows, reinterpret_cast<uint2*>(ix->shadow), nullptr);
+        rc = launch_normalize(ix->dtype, dvec, m, ix->dim, ix->dpad, normalize, dslot, 0, ix->rows, nullptr, nullptr);
+        // (one synchronisation per piece: the staging buffers are reused by the next piece, and the call is synchronous by contract)
         if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = fail(CODD_KNN_EDEVICE, "ingest kernel failed%s");
     }
-    (void)hipFree(dvec);
-    (void)hipFree(dslot);
+    ix->rows_event_set = false;  // (everything is complete on the device)
     if (rc == 0) {
         if (max_slot + 1 > ix->count) ix->count = max_slot + 1;
         rows_written(ix, min_slot, max_slot + 1);
@@ -1653,9 +1760,22 @@ int codd_knn_upsert_device(codd_knn_index* ix, int64_t first_slot, const float* 
         int rc = grow_rows(ix, first_slot + n, /*exact=*/false);
         if (rc != 0) return rc;
     }
-    int rc = launch_normalize(ix->dtype, dev_vecs, n, ix->dim, ix->dpad, normalize, nullptr, first_slot, ix->rows,
-                              reinterpret_cast<uint2*>(ix->shadow), (hipStream_t)stream);
+    hipStream_t wst = (hipStream_t)stream;
+    // device-side ordering against searches still in flight on OTHER streams (the call is exclusive on the host, but their
+    // kernels may still be reading the rows this launch overwrites): the writing stream waits for every searching stream
+    for (WorkSlot& w : ix->slots) {
+        if (!w.used || w.stream == wst) continue;
+        if (!w.handover) HIP_TRY(hipEventCreateWithFlags(&w.handover, hipEventDisableTiming));
+        if (hipEventRecord(w.handover, w.stream) == hipSuccess) HIP_TRY(hipStreamWaitEvent(wst, w.handover, 0));
+        else (void)hipGetLastError();  // (a stream that no longer exists has nothing in flight)
+    }
+    int rc = launch_normalize(ix->dtype, dev_vecs, n, ix->dim, ix->dpad, normalize, nullptr, first_slot, ix->rows, nullptr, wst);
     if (rc != 0) return rc;
+    // ... and searches on other streams wait for this write (wait_rows)
+    if (!ix->rows_ready) HIP_TRY(hipEventCreateWithFlags(&ix->rows_ready, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ix->rows_ready, wst));
+    ix->rows_stream = wst;
+    ix->rows_event_set = true;
     if (first_slot + n > ix->count) ix->count = first_slot + n;
     rows_written(ix, first_slot, first_slot + n);
     if (!normalize) ix->all_normalized = false;
@@ -1672,15 +1792,27 @@ int codd_knn_load_rows(codd_knn_index* ix, int64_t first_slot, const void* host_
     if (rc != 0) return rc;
     const size_t row_bytes = (size_t)ix->dpad * elem_size(ix->dtype);
     HIP_TRY(hipMemcpy((char*)ix->rows + (size_t)first_slot * row_bytes, host_rows, (size_t)n * row_bytes, hipMemcpyHostToDevice));
+    // the loaded rows are taken as they are, so their norms are checked: the filters stay on only for unit rows
+    // (tolerance = the storage type's rounding of a unit vector)
+    unsigned* dev_bits = nullptr;
+    HIP_TRY(hipMalloc((void**)&dev_bits, sizeof(unsigned)));
+    hipError_t e = hipMemset(dev_bits, 0, sizeof(unsigned));
     const dim3 grid((unsigned)((n + 3) / 4)), block(256);
-    uint2* sh = reinterpret_cast<uint2*>(ix->shadow);
-    switch (ix->dtype) {
-        case DT_F32: hipLaunchKernelGGL(shadow_from_rows_kernel<DT_F32>, grid, block, 0, nullptr, ix->rows, first_slot, n, ix->dpad, sh); break;
-        case DT_BF16: hipLaunchKernelGGL(shadow_from_rows_kernel<DT_BF16>, grid, block, 0, nullptr, ix->rows, first_slot, n, ix->dpad, sh); break;
-        default: hipLaunchKernelGGL(shadow_from_rows_kernel<DT_F16>, grid, block, 0, nullptr, ix->rows, first_slot, n, ix->dpad, sh); break;
+    if (e == hipSuccess) {
+        switch (ix->dtype) {
+            case DT_F32: hipLaunchKernelGGL(row_norm_check_kernel<DT_F32>, grid, block, 0, nullptr, ix->rows, first_slot, n, ix->dpad, dev_bits); break;
+            case DT_BF16: hipLaunchKernelGGL(row_norm_check_kernel<DT_BF16>, grid, block, 0, nullptr, ix->rows, first_slot, n, ix->dpad, dev_bits); break;
+            default: hipLaunchKernelGGL(row_norm_check_kernel<DT_F16>, grid, block, 0, nullptr, ix->rows, first_slot, n, ix->dpad, dev_bits); break;
+        }
+        e = hipGetLastError();
     }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipDeviceSynchronize());
+    float worst = 0.0f;
+    if (e == hipSuccess) e = hipMemcpy(&worst, dev_bits, sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(dev_bits);
+    if (e != hipSuccess) return fail(CODD_KNN_EDEVICE, "norm check of the loaded rows failed: %s", hipGetErrorString(e));
+    const float tol = ix->dtype == DT_F32 ? 1e-4f : (ix->dtype == DT_BF16 ? 4e-3f : 6e-4f);
+    if (!(worst <= tol)) ix->all_normalized = false;
+    ix->rows_event_set = false;
     if (first_slot + n > ix->count) ix->count = first_slot + n;
     rows_written(ix, first_slot, first_slot + n);
     return CODD_KNN_OK;
@@ -1742,11 +1874,12 @@ int codd_knn_merge_shards(int device, const uint64_t* dev_keys_in, int G, int B,
 
 int codd_knn_approx_scores(codd_knn_index* ix, const float* dev_queries, int B, float* dev_scores, void* stream) {
     if (!ix || !dev_queries || !dev_scores || B < 1 || B > kTileQ) return fail(CODD_KNN_EINVAL, "bad debug arguments%s");
-    if (ix->count < 1 || !ix->shadow) return fail(CODD_KNN_EINVAL, "empty index%s");
+    if (ix->count < 1) return fail(CODD_KNN_EINVAL, "empty index%s");
     DeviceGuard guard(ix->device);
     hipStream_t st = (hipStream_t)stream;
     WorkScope work(ix, st);
     int rc;
+    if ((rc = wait_rows(ix, st)) != 0) return rc;
     if ((rc = ensure_buf(&ix->qn, &ix->qn_cap, (int64_t)B * ix->dpad)) != 0) return rc;
     if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
     if (ix->shadow8_enabled && B <= 32 && CODD_MFMA16) {
@@ -1766,6 +1899,7 @@ int codd_knn_approx_scores(codd_knn_index* ix, const float* dev_queries, int B, 
         HIP_TRY(hipGetLastError());
         return CODD_KNN_OK;
     }
+    if ((rc = ensure_shadow(ix, st)) != 0) return rc;
     if ((rc = launch_normalize(DT_F32, dev_queries, B, ix->dim, ix->dpad, 1, nullptr, 0, ix->qn, nullptr, st)) != 0) return rc;
     hipLaunchKernelGGL(qfrag_kernel, dim3((kTileQ * (ix->dpad / 8) + 255) / 256), dim3(256), 0, st, ix->qn, B, ix->dpad, ix->qfrag,
                        (unsigned*)nullptr, 0);
@@ -1809,17 +1943,57 @@ int codd_knn_ivf_install(codd_knn_index* ix, const float* dev_centroids, int nli
 
     const size_t row_bytes = (size_t)ix->dpad * elem_size(ix->dtype);
     const int64_t n = ix->count;
-    HIP_TRY(hipMalloc(&ix->rows_ivf, (size_t)n * row_bytes));
-    HIP_TRY(hipMalloc((void**)&ix->ivf_ids, (size_t)n * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc((void**)&ix->ivf_offsets, (size_t)(nlist + 1) * sizeof(int64_t)));
-    HIP_TRY(hipMemcpyAsync(ix->ivf_offsets, dev_offsets, (size_t)(nlist + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, reinterpret_cast<const uint4*>(ix->rows), dev_perm, n,
-                       (int)(row_bytes / 16), reinterpret_cast<uint4*>(ix->rows_ivf), ix->ivf_ids);
-    HIP_TRY(hipGetLastError());
-    int rc = codd_knn_create(&ix->coarse, ix->device, ix->dim, DT_F32, CODD_KNN_METRIC_COSINE);
-    if (rc != 0) return rc;
-    if ((rc = codd_knn_upsert_device(ix->coarse, 0, dev_centroids, nlist, 1, stream)) != 0) return rc;
-    HIP_TRY(hipStreamSynchronize(st));
+    // validate the caller's tables before anything indexes memory with them: offsets on the host (nlist + 1 values),
+    // the permutation on the device
+    {
+        std::vector<int64_t> off((size_t)nlist + 1);
+        HIP_TRY(hipMemcpyAsync(off.data(), dev_offsets, off.size() * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        bool ok = off[0] == 0 && off[(size_t)nlist] == n;
+        for (int l = 0; ok && l < nlist; ++l) ok = off[(size_t)l] <= off[(size_t)l + 1];
+        if (!ok) return fail(CODD_KNN_EINVAL, "ivf_install: offsets must start at 0, never decrease and end at the row count%s");
+        unsigned* bad = nullptr;
+        HIP_TRY(hipMalloc((void**)&bad, sizeof(unsigned)));
+        hipError_t e = hipMemsetAsync(bad, 0, sizeof(unsigned), st);
+        unsigned host_bad = 1;
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(perm_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dev_perm, n, bad);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(&host_bad, bad, sizeof(unsigned), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipFree(bad);
+        if (e != hipSuccess) return fail(CODD_KNN_EDEVICE, "ivf_install: permutation check failed: %s", hipGetErrorString(e));
+        if (host_bad) return fail(CODD_KNN_EINVAL, "ivf_install: permutation entries must lie in [0, count)%s");
+    }
+    auto drop_partial = [&]() {  // a failed install leaves no half-built layout (and no leak) behind
+        void* part[] = {ix->rows_ivf, ix->ivf_ids, ix->ivf_offsets};
+        for (void* b_ : part)
+            if (b_) (void)hipFree(b_);
+        ix->rows_ivf = nullptr; ix->ivf_ids = nullptr; ix->ivf_offsets = nullptr;
+        if (ix->coarse) { (void)codd_knn_destroy(ix->coarse); ix->coarse = nullptr; }
+    };
+    int rc = CODD_KNN_OK;
+    hipError_t he = hipMalloc(&ix->rows_ivf, (size_t)n * row_bytes);
+    if (he == hipSuccess) he = hipMalloc((void**)&ix->ivf_ids, (size_t)n * sizeof(uint32_t));
+    if (he == hipSuccess) he = hipMalloc((void**)&ix->ivf_offsets, (size_t)(nlist + 1) * sizeof(int64_t));
+    if (he == hipSuccess) he = hipMemcpyAsync(ix->ivf_offsets, dev_offsets, (size_t)(nlist + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, st);
+    if (he == hipSuccess) {
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, reinterpret_cast<const uint4*>(ix->rows), dev_perm, n,
+                           (int)(row_bytes / 16), reinterpret_cast<uint4*>(ix->rows_ivf), ix->ivf_ids);
+        he = hipGetLastError();
+    }
+    if (he != hipSuccess) {
+        drop_partial();
+        return fail(he == hipErrorOutOfMemory ? CODD_KNN_ENOMEM : CODD_KNN_EDEVICE, "ivf_install: building the list layout failed: %s", hipGetErrorString(he));
+    }
+    rc = codd_knn_create(&ix->coarse, ix->device, ix->dim, DT_F32, CODD_KNN_METRIC_COSINE);
+    if (rc == 0) rc = codd_knn_upsert_device(ix->coarse, 0, dev_centroids, nlist, 1, stream);
+    if (rc == 0 && hipStreamSynchronize(st) != hipSuccess) rc = fail(CODD_KNN_EDEVICE, "ivf_install: device work failed%s");
+    if (rc != 0) {
+        drop_partial();
+        return rc;
+    }
     ix->ivf_nlist = nlist;
     ix->ivf_count = n;
     ix->ivf_epoch = ix->epoch;
@@ -1839,6 +2013,7 @@ int codd_knn_ivf_search(codd_knn_index* ix, const float* dev_queries, int B, int
     hipStream_t st = (hipStream_t)stream;
     WorkScope work(ix, st), work_coarse(ix->coarse, st);
     int rc;
+    if ((rc = wait_rows(ix, st)) != 0) return rc;
     if ((rc = ensure_buf(&ix->qn, &ix->qn_cap, (int64_t)B * ix->dpad)) != 0) return rc;
     if ((rc = ensure_buf(&ix->probe_keys, &ix->probe_cap, (int64_t)B * nprobe)) != 0) return rc;
     if ((rc = launch_normalize(DT_F32, dev_queries, B, ix->dim, ix->dpad, 1, nullptr, 0, ix->qn, nullptr, st)) != 0) return rc;
@@ -1908,9 +2083,18 @@ int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {
         ix->cooldown_left = 0;
         return CODD_KNN_OK;
     }
-    if (strcmp(key, "exp_slack_pct") == 0) {  // diagnostic: see exp_slack_scale
+#if CODD_EXPERIMENTS
+    if (strcmp(key, "exp_slack_pct") == 0) {  // what-if timing only, experiment builds only: < 100 makes the int8 filter UNSOUND
         if (value < 1 || value > 100) return fail(CODD_KNN_EINVAL, "exp_slack_pct must be in [1,100]%s");
         ix->exp_slack_scale = (float)value / 100.0f;
+        return CODD_KNN_OK;
+    }
+#endif
+    if (strcmp(key, "all_normalized") == 0) {
+        // 0: the caller knows of rows that are not unit vectors (a persisted index written with normalize = 0): both filters
+        // off, every search takes the exact scan.  The flag cannot be switched back on from outside.
+        if (value != 0) return fail(CODD_KNN_EINVAL, "all_normalized can only be cleared (0)%s");
+        ix->all_normalized = false;
         return CODD_KNN_OK;
     }
     if (strcmp(key, "i8v2") == 0) {
@@ -1991,6 +2175,8 @@ int codd_knn_get_stat(const codd_knn_index* ix, const char* key, int64_t* out) {
     else if (strcmp(key, "last_scan_blocks") == 0) *out = ix->stat_last_scan_blocks;
     else if (strcmp(key, "filter_passes") == 0) *out = ix->stat_filter_passes;
     else if (strcmp(key, "shadow8_builds") == 0) *out = ix->stat_shadow8_builds;
+    else if (strcmp(key, "shadow16_builds") == 0) *out = ix->stat_shadow_builds;
+    else if (strcmp(key, "all_normalized") == 0) *out = ix->all_normalized ? 1 : 0;
     else if (strcmp(key, "shadow8_passes") == 0) *out = ix->stat_shadow8_passes;
     else if (strcmp(key, "i8v2_passes") == 0) *out = ix->stat_i8v2_passes;
     else if (strcmp(key, "shadow8_cooldowns") == 0) *out = ix->stat_cooldowns;

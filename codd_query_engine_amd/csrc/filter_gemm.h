@@ -86,6 +86,13 @@ __device__ __forceinline__ int acc_row(int r, int lane) {
     return CODD_MFMA16 ? 4 * (lane >> 4) + r : 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
 }
 // build-time experiment switches (defaults = the shipped configuration)
+#ifndef CODD_EXPERIMENTS
+#define CODD_EXPERIMENTS 0
+#endif
+#if !CODD_EXPERIMENTS && (defined(CODD_NO_EPILOGUE) || defined(CODD_EXP_SAME_TILE) || defined(CODD_EXP_NO_QSTAGE) || defined(CODD_EXP_NB) || \
+                          defined(CODD_EXP_NO_HITS) || defined(CODD_EXP_NO_LDSREAD) || defined(CODD_EXP_NO_FLUSH) || defined(CODD_EXP_NO_BARRIER))
+#error "the CODD_EXP_* / CODD_NO_EPILOGUE switches return wrong results or race: they exist only in -DCODD_EXPERIMENTS=1 builds (build_variant)"
+#endif
 #ifndef CODD_QS
 #define CODD_QS 2            // 64-wide query K-slices per LDS stage = K-steps per workgroup barrier
 #endif

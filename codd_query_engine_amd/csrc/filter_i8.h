@@ -29,6 +29,11 @@
 #pragma once
 #include "filter_gemm.h"
 
+#if !CODD_EXPERIMENTS && (defined(CODD_I8_EXP_NOEPI) || defined(CODD_I8_EXP_NODMA) || defined(CODD_I8_EXP_SAMETILE) || defined(CODD_I8_EXP_NOBARRIER) || \
+                          defined(CODD_I8_EXP_NOBREAD))
+#error "the CODD_I8_EXP_* switches return wrong results or race: they exist only in -DCODD_EXPERIMENTS=1 builds (build_variant)"
+#endif
+
 namespace codd {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));

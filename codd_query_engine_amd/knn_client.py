@@ -215,6 +215,10 @@ class Collection:
         if self._engine is not None and n:
             rows = self._engine.read_rows(0, n)
             manifest.update(dim=self._engine.dim, padded_dim=int(rows.shape[1]), dtype=getattr(self._engine, "dtype", "f32"))
+            # whether every stored row is a unit vector: both MFMA filters assume it, and a reader of this generation has no
+            # other way to know that some rows were written with normalize = 0 (its own norm check of rows.bin comes on top)
+            stat = getattr(self._engine, "stat", None)
+            manifest["all_normalized"] = bool(stat("all_normalized")) if callable(stat) else True
             rows.tofile(os.path.join(tmp, "rows.bin"))
         with open(os.path.join(tmp, "ids.json"), "w") as f:
             json.dump(self._ids, f, ensure_ascii=False)
@@ -267,6 +271,8 @@ class Collection:
             if getattr(engine, "dtype", dtype) != dtype:
                 raise ValueError(f"{gdir}: stored dtype {dtype} does not match the client's dtype {engine.dtype}")
             engine.load_rows(rows, 0)
+            if manifest.get("all_normalized") is False and callable(getattr(engine, "set_option", None)):
+                engine.set_option("all_normalized", 0)
         old = self._engine
         self._engine = engine
         if old is not None and hasattr(old, "close"):

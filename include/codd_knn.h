@@ -79,7 +79,12 @@ int codd_knn_reserve(codd_knn_index* index, int64_t rows);
  *           (overwrite).  normalize != 0 scales each vector to unit L2 norm first
  *           (always what the façade asks for; 0 is for callers that already did).
  *           Storage grows as needed.  The host variant stages through a bounded device
- *           buffer and is synchronous; the device variant writes slots [first_slot, first_slot+n).
+ *           buffer (kept by the index between calls) and is synchronous; the device variant
+ *           writes slots [first_slot, first_slot+n) asynchronously on `stream`: it is ordered on
+ *           the device behind every search already enqueued on other streams of this index, and
+ *           every later search on another stream waits for it on the device (no host
+ *           synchronisation either way).  The `dev_vecs` buffer must stay valid until `stream`
+ *           has run the call.
  */
 int codd_knn_upsert_host(codd_knn_index* index, const int64_t* host_slots, const float* host_vecs,
                          int64_t n, int normalize);
@@ -90,7 +95,9 @@ int codd_knn_upsert_device(codd_knn_index* index, int64_t first_slot, const floa
  * Counterpart of codd_knn_read_rows for loading a persisted index (the role of the Chroma
  * server's docker volume, docker-compose.yml:8-9): `host_rows` are n stored rows exactly as
  * codd_knn_read_rows returned them (storage dtype, padded width, already normalised); they are
- * copied into slots [first_slot, first_slot+n) and the bf16 shadow is rebuilt.  Synchronous.
+ * copied into slots [first_slot, first_slot+n).  Their norms are checked on the device: if any row is
+ * not a unit vector (within the storage type's rounding) the index behaves as after an upsert with
+ * normalize = 0 — both filters off, every search an exact scan ("all_normalized" stat = 0).  Synchronous.
  */
 int codd_knn_load_rows(codd_knn_index* index, int64_t first_slot, const void* host_rows, int64_t n);
 
@@ -170,21 +177,28 @@ int codd_knn_ivf_search(codd_knn_index* index, const float* dev_queries, int B, 
  *            smaller batches filter when rows * B reaches it): when the filter path is taken;
  *            "sample_div" (40: about 1/40 of the tiles set the per-query thresholds, never
  *            fewer than one tile per CU once the corpus has two rounds of tiles), "sample_tiles"
- *            (4096: upper bound on that number), "hit_cap" (per-query
+ *            (4096: upper bound on that number), "hit_cap" (131072: per-query
  *            candidate capacity; overflow falls back to the exact scan);
+ *            "all_normalized" (write 0 only: the caller knows of stored rows that are not unit
+ *            vectors, e.g. a persisted index whose manifest says so: filters off for good);
  *            "shadow8" (1: batches of <= "shadow8_max_batch" (256) queries are filtered through an
  *            int8 copy of the corpus, 1 byte per element, derived lazily from the stored rows and
  *            kept up to date incrementally; results stay exact; an index whose worst row quantises
  *            badly — error norm above 0.04 — keeps the bf16 filter; so does, for the next
  *            "shadow8_cooldown" (256) searches, an index whose int8 passes leave more than
  *            "shadow8_max_surv" (4000) survivors per query or send queries to the fallback: dense
- *            clusters), "sample_div8" (20), "resident_q" (1: rows of <= 512 int8 elements keep the
- *            query block in LDS for the whole launch);
+ *            clusters — unless the bf16 passes are seen to leave just as many), "sample_div8" (20),
+ *            "resident_q" (1: rows of <= 512 int8 elements keep the query block in LDS for the
+ *            whole launch), "i8v2" (1: batches of 129..256 queries on rows of more than 512
+ *            elements take the second-generation int8 kernel, csrc/filter_i8.h; 2: from 384
+ *            elements on; 0: never);
  *            "profile" = N keeps N (start, stop) HIP-event pairs, one per heavy-kernel launch,
  *            recorded on the launch stream (0 = off; resets the log)
  *   stats  : "searches", "scan_launches", "last_scan_blocks", "filter_passes",
  *            "fallback_queries", "filter_hits", "filter_survivors", "capacity_rows",
- *            "device_bytes", "num_cus", "workspaces" (stream workspaces in use), "shadow8_builds", "shadow8_passes", "shadow8_cooldowns", "shadow8_eps_r_micro", and per kernel K in {scan, filter, sample, finalize}:
+ *            "device_bytes", "num_cus", "workspaces" (stream workspaces in use), "shadow8_builds", "shadow8_passes", "i8v2_passes",
+ *            "shadow16_builds" (the bf16 shadow is built lazily, by the first search that needs it), "all_normalized",
+ *            "shadow8_cooldowns", "shadow8_eps_r_micro", and per kernel K in {scan, filter, sample, finalize}:
  *            "events:K", "time_ns:K" (sum of the recorded launches; syncs on the last event)
  */
 int codd_knn_set_option(codd_knn_index* index, const char* key, int64_t value);

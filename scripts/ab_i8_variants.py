@@ -22,7 +22,8 @@ if sys.argv[1] == "build":
     from codd_query_engine_amd import build as b
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(3) as ex:
-        list(ex.map(lambda kv: b.build_variant(kv[0], kv[1]), VARIANTS.items()))
+        # the *_EXP_* switches break results on purpose: they only compile in experiment builds
+        list(ex.map(lambda kv: b.build_variant(kv[0], {**kv[1], **({'CODD_EXPERIMENTS': 1} if any('_EXP_' in k for k in kv[1]) else {})}), VARIANTS.items()))
     print("built", list(VARIANTS))
 else:
     rows = sys.argv[2] if len(sys.argv) > 2 else "4000000"

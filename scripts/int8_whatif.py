@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""What would the int8 filter cost at large batches if its thresholds were tighter? (development tool; the scaled
+"""(needs an experiment build: build_variant("exp", {"CODD_EXPERIMENTS": 1}) and CODD_KNN_LIB=...: "exp_slack_pct" does not exist in the shipped library)
+What would the int8 filter cost at large batches if its thresholds were tighter? (development tool; the scaled
 slack is UNSOUND, timing only)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -11,9 +11,16 @@ from codd_query_engine_amd.wire import cli_main, create_app, make_search_relevan
 from tests._oracle_engine import OracleEngine
 
 
-@pytest.fixture()
-def search_client():
-    store = MetricsSemanticMetadataStore(KnnClient(engine_factory=lambda dim: OracleEngine(dim)))
+def _client(kind):
+    if kind == "hip-engine":
+        return KnnClient(device="cuda:0")
+    return KnnClient(engine_factory=lambda dim: OracleEngine(dim))
+
+
+@pytest.fixture(params=["checker-engine", pytest.param("hip-engine", marks=pytest.mark.gpu)])
+def search_client(request):
+    """Every shim test runs on the checker engine (CPU) and, on the GPU box, on the HIP engine: route -> store -> C ABI."""
+    store = MetricsSemanticMetadataStore(_client(request.param))
     store.index_metadata("prod", {"metric_name": "http_request_duration_seconds", "description": "HTTP request latency in seconds",
                                   "category": "application", "golden_signal_type": "latency", "type": "histogram"})
     store.index_metadata("prod", {"metric_name": "node_memory_MemFree_bytes", "description": "Free memory in bytes", "category": "infrastructure"})
