@@ -185,7 +185,10 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const void* __restrict__
                                                         const float* __restrict__ qn, int nq_arg, int k,
                                                         uint32_t row_base, u64* __restrict__ partial,
                                                         int64_t partial_stride_q, const unsigned* __restrict__ qlist,
-                                                        const unsigned* __restrict__ qcount_ptr) {
+                                                        const unsigned* __restrict__ qcount_ptr, unsigned* __restrict__ merge_done = nullptr,
+                                                        u64* __restrict__ merged_keys = nullptr, float* __restrict__ merged_dist = nullptr,
+                                                        int64_t* __restrict__ merged_rows = nullptr,
+                                                        unsigned long long* __restrict__ count_total = nullptr) {
     typedef RowTraits<DT> RT;
     constexpr int E = RT::E;
     const int lane = lane_id();
@@ -282,6 +285,42 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const void* __restrict__
     }
     __syncthreads();  // the LDS lists are rewritten by the next group
     }  // group loop
+
+    // LISTED mode with `merge_done`: the block that finishes last merges every queued query's per-block partials and writes
+    // the answers into the queries' own slots — the fallback is ONE launch (an empty queue, the normal case, costs one
+    // empty launch and touches no counter).  Hand-off: every block's stores, a device-scope fence, the arrival ticket;
+    // the last arriver fences again before it reads the other blocks' partials.
+    if (qcount_ptr && merge_done && total > 0) {
+        __shared__ unsigned s_last;
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(merge_done, 1u) == gridDim.x - 1 ? 1u : 0u;
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();
+        if (threadIdx.x == 0 && count_total) atomicAdd(count_total, (unsigned long long)total);
+        const int64_t m = (int64_t)gridDim.x * k;
+        for (int qi = wave; qi < total; qi += 4) {
+            const u64* src = partial + (int64_t)qi * partial_stride_q;
+            WaveTopK<SLOTS> M;
+            M.init();
+            for (int64_t i0 = 0; i0 < m; i0 += kWave) {
+                const int64_t i = i0 + lane;
+                M.offer_lanes(i < m ? src[i] : 0ull, k, lane);
+            }
+            const int64_t o = (int64_t)qlist[qi] * k;
+#pragma unroll
+            for (int s2 = 0; s2 < SLOTS; ++s2) {
+                const int rank = s2 * kWave + lane;
+                if (rank < k) {
+                    const u64 key = M.v[s2];
+                    if (merged_keys) merged_keys[o + rank] = key;
+                    if (merged_dist) merged_dist[o + rank] = key ? 1.0f - key_score(key) : INFINITY;
+                    if (merged_rows) merged_rows[o + rank] = key ? (int64_t)key_row(key) : (int64_t)-1;
+                }
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -648,7 +687,8 @@ struct FilterCtl {
     unsigned hit_cnt[kTileQ * kHitCntStride];
     unsigned flags[FLAG_WORDS];
     unsigned fb_count;         // queries queued for the exact-scan fallback ...
-    unsigned pad_[3];
+    unsigned fb_done;          // ... blocks of the fallback scan that have finished (the last one merges)
+    unsigned pad_[2];
     unsigned fb_list[kTileQ];  // ... and which ones
 };
 
@@ -729,6 +769,7 @@ struct codd_knn_index : WorkBufs {
     int resident_q = 1;           // rows of <= 512 int8 elements: the query block stays in LDS ("resident_q" option)
     int i8v2 = 1;                 // full query blocks on rows of > 512 elements take i8_tile_kernel (filter_i8.h); 2: from 384 elements on; 0: never
     int sample_div8 = 20;         // its thresholds come from a larger sample (the int8 slack is ~5x the bf16 one)
+    int sample_rounds8 = 3;       // ... of at least this many rounds of workgroups (one tile each) when the batch has more than 32 queries
     uint4* shadow8 = nullptr;
     int64_t shadow8_rows = 0;     // rows the allocation covers (multiple of 256)
     float* rscale = nullptr;      // [shadow8_rows]
@@ -966,14 +1007,19 @@ struct ScanArgs {
     int64_t stride_q;
     const unsigned* qlist = nullptr;   // LISTED mode (device-side fallback queue)
     const unsigned* qcount = nullptr;
+    unsigned* merge_done = nullptr;    // LISTED mode: the last block merges and writes the answers (one launch)
+    u64* merged_keys = nullptr;
+    float* merged_dist = nullptr;
+    int64_t* merged_rows = nullptr;
+    unsigned long long* count_total = nullptr;
 };
 
 template <int DT, int NB, int NITER>
 void launch_scan_slots(int slots, dim3 grid, size_t lds, hipStream_t st, const ScanArgs& a) {
     if (slots == 1)
-        hipLaunchKernelGGL((scan_topk_kernel<DT, NB, NITER, 1>), grid, dim3(256), lds, st, a.rows, a.n, a.dpad, a.qn, a.nq, a.k, a.row_base, a.partial, a.stride_q, a.qlist, a.qcount);
+        hipLaunchKernelGGL((scan_topk_kernel<DT, NB, NITER, 1>), grid, dim3(256), lds, st, a.rows, a.n, a.dpad, a.qn, a.nq, a.k, a.row_base, a.partial, a.stride_q, a.qlist, a.qcount, a.merge_done, a.merged_keys, a.merged_dist, a.merged_rows, a.count_total);
     else
-        hipLaunchKernelGGL((scan_topk_kernel<DT, NB, NITER, 2>), grid, dim3(256), lds, st, a.rows, a.n, a.dpad, a.qn, a.nq, a.k, a.row_base, a.partial, a.stride_q, a.qlist, a.qcount);
+        hipLaunchKernelGGL((scan_topk_kernel<DT, NB, NITER, 2>), grid, dim3(256), lds, st, a.rows, a.n, a.dpad, a.qn, a.nq, a.k, a.row_base, a.partial, a.stride_q, a.qlist, a.qcount, a.merge_done, a.merged_keys, a.merged_dist, a.merged_rows, a.count_total);
 }
 
 template <int DT, int NB>
@@ -1090,24 +1136,25 @@ float filter_eps(const codd_knn_index* ix) {
 
 template <int DT, int NITER>
 void launch_finalize_slots(int slots, int B, hipStream_t st, const codd_knn_index* ix, const float* qn, int k, float two_eps,
-                           uint32_t row_base, u64* out_keys, const float* two_eps_q, int nparts, u64* part_keys) {
+                           uint32_t row_base, u64* out_keys, const float* two_eps_q, int nparts, u64* part_keys, float* out_dist, int64_t* out_rows) {
     FilterCtl* c = ix->ctl;
     if (slots == 1)
         hipLaunchKernelGGL((finalize_kernel<DT, NITER, 1>), dim3(B, nparts), dim3(256), 0, st, ix->rows, ix->dpad, qn, ix->hits, c->hit_cnt,
-                           ix->hit_cap_q, c->flags, k, two_eps, row_base, out_keys, &c->fb_count, c->fb_list, ix->dstats, two_eps_q, part_keys);
+                           ix->hit_cap_q, c->flags, k, two_eps, row_base, out_keys, &c->fb_count, c->fb_list, ix->dstats, two_eps_q, part_keys, out_dist, out_rows);
     else
         hipLaunchKernelGGL((finalize_kernel<DT, NITER, 2>), dim3(B, nparts), dim3(256), 0, st, ix->rows, ix->dpad, qn, ix->hits, c->hit_cnt,
-                           ix->hit_cap_q, c->flags, k, two_eps, row_base, out_keys, &c->fb_count, c->fb_list, ix->dstats, two_eps_q, part_keys);
+                           ix->hit_cap_q, c->flags, k, two_eps, row_base, out_keys, &c->fb_count, c->fb_list, ix->dstats, two_eps_q, part_keys, out_dist, out_rows);
 }
 
 template <int DT>
 int launch_finalize(int niter, int slots, int B, hipStream_t st, const codd_knn_index* ix, const float* qn, int k, float two_eps,
-                    uint32_t row_base, u64* out_keys, const float* two_eps_q = nullptr, int nparts = 1, u64* part_keys = nullptr) {
+                    uint32_t row_base, u64* out_keys, const float* two_eps_q = nullptr, int nparts = 1, u64* part_keys = nullptr,
+                    float* out_dist = nullptr, int64_t* out_rows = nullptr) {
     switch (niter) {
-        case 1: launch_finalize_slots<DT, 1>(slots, B, st, ix, qn, k, two_eps, row_base, out_keys, two_eps_q, nparts, part_keys); break;
-        case 2: launch_finalize_slots<DT, 2>(slots, B, st, ix, qn, k, two_eps, row_base, out_keys, two_eps_q, nparts, part_keys); break;
-        case 3: launch_finalize_slots<DT, 3>(slots, B, st, ix, qn, k, two_eps, row_base, out_keys, two_eps_q, nparts, part_keys); break;
-        case 4: launch_finalize_slots<DT, 4>(slots, B, st, ix, qn, k, two_eps, row_base, out_keys, two_eps_q, nparts, part_keys); break;
+        case 1: launch_finalize_slots<DT, 1>(slots, B, st, ix, qn, k, two_eps, row_base, out_keys, two_eps_q, nparts, part_keys, out_dist, out_rows); break;
+        case 2: launch_finalize_slots<DT, 2>(slots, B, st, ix, qn, k, two_eps, row_base, out_keys, two_eps_q, nparts, part_keys, out_dist, out_rows); break;
+        case 3: launch_finalize_slots<DT, 3>(slots, B, st, ix, qn, k, two_eps, row_base, out_keys, two_eps_q, nparts, part_keys, out_dist, out_rows); break;
+        case 4: launch_finalize_slots<DT, 4>(slots, B, st, ix, qn, k, two_eps, row_base, out_keys, two_eps_q, nparts, part_keys, out_dist, out_rows); break;
         default: return fail(CODD_KNN_ENOTSUP, "row too wide for the finalize kernel%s");
     }
     HIP_TRY(hipGetLastError());
@@ -1156,7 +1203,7 @@ int64_t sample_tile_count(const codd_knn_index* ix, int64_t ntiles, int k, bool 
         // the int8 filter pays more per hit (wider slack, more of them) and less per sampled tile: three rounds of
         // workgroups where that is still under a quarter of the corpus (scripts/int8_sweep.py: 1/6 of a 1.25M-row
         // shard, 1/20 of 10M rows; twice as sparse for <= 32 queries, whose sample is a pure byte stream)
-        const int64_t rounds = (nbq == 1 ? 1 : 3) * (int64_t)ix->num_cus;
+        const int64_t rounds = (nbq == 1 ? 1 : ix->sample_rounds8) * (int64_t)ix->num_cus;
         const int64_t floor8 = rounds < ntiles / 4 ? rounds : ntiles / 4;
         if (ts < floor8) ts = floor8;
     }
@@ -1291,8 +1338,9 @@ int ensure_shadow8(codd_knn_index* ix, hipStream_t st) {
 }
 
 // one pass of <= 256 queries through sample -> threshold -> filter -> finalize (+ exact fallback)
-int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row_base, u64* keys_out, hipStream_t st,
-                bool prepared = false, bool use8 = false) {
+// keys_out and / or (dist_out, rows_out): what the caller wants written per query (any may be null)
+int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row_base, u64* keys_out, float* dist_out, int64_t* rows_out,
+                hipStream_t st, bool prepared = false, bool use8 = false) {
     const int64_t n = ix->count;
     const int nsteps = use8 ? dpad8_of(ix) / 128 : ix->dpad / 64;
     const uint4* shadow = use8 ? ix->shadow8 : ix->shadow;
@@ -1453,17 +1501,17 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     {
         EvScope ev(ix, EV_FINALIZE, st);
         switch (ix->dtype) {
-            case DT_F32: rc = launch_finalize<DT_F32>(niter, slots, nq, st, ix, qn, k, 2.0f * eps, row_base, keys_out, slack_q, nparts, ix->partial); break;
-            case DT_BF16: rc = launch_finalize<DT_BF16>(niter, slots, nq, st, ix, qn, k, 2.0f * eps, row_base, keys_out, slack_q, nparts, ix->partial); break;
-            default: rc = launch_finalize<DT_F16>(niter, slots, nq, st, ix, qn, k, 2.0f * eps, row_base, keys_out, slack_q, nparts, ix->partial); break;
+            case DT_F32: rc = launch_finalize<DT_F32>(niter, slots, nq, st, ix, qn, k, 2.0f * eps, row_base, keys_out, slack_q, nparts, ix->partial, dist_out, rows_out); break;
+            case DT_BF16: rc = launch_finalize<DT_BF16>(niter, slots, nq, st, ix, qn, k, 2.0f * eps, row_base, keys_out, slack_q, nparts, ix->partial, dist_out, rows_out); break;
+            default: rc = launch_finalize<DT_F16>(niter, slots, nq, st, ix, qn, k, 2.0f * eps, row_base, keys_out, slack_q, nparts, ix->partial, dist_out, rows_out); break;
         }
     }
     if (rc != 0) return rc;
-    if (nparts > 1 && (rc = launch_merge(ix->partial, nq, (int64_t)nparts * k, (int64_t)nparts * k, k, keys_out, nullptr, nullptr, st)) != 0) return rc;
+    if (nparts > 1 && (rc = launch_merge(ix->partial, nq, (int64_t)nparts * k, (int64_t)nparts * k, k, keys_out, dist_out, rows_out, st)) != 0) return rc;
 
-    // exact-scan fallback for the queries finalize queued (normally none), entirely on the device: the
-    // scan walks the queue (an empty queue costs two empty launches), the merge writes each answer into
-    // its query's slot.  No host round trip: the whole search stays asynchronous on `st`.
+    // exact-scan fallback for the queries finalize queued (normally none), entirely on the device and in ONE launch: the
+    // scan walks the queue (an empty queue costs one empty launch), its last block merges the per-block partials and
+    // writes each answer into its query's slot.  No host round trip: the whole search stays asynchronous on `st`.
     {
         int nit;
         int64_t blocks;
@@ -1472,6 +1520,11 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
         const int64_t stride_q = blocks * k;
         if ((rc = ensure_buf(&ix->fb_partial, &ix->fb_partial_cap, (int64_t)kTileQ * stride_q)) != 0) return rc;
         ScanArgs a{ix->rows, n, ix->dpad, qn, 0, k, row_base, ix->fb_partial, stride_q, ix->ctl->fb_list, &ix->ctl->fb_count};
+        a.merge_done = &ix->ctl->fb_done;
+        a.merged_keys = keys_out;
+        a.merged_dist = dist_out;
+        a.merged_rows = rows_out;
+        a.count_total = &ix->dstats[2];
         {
             EvScope ev(ix, EV_SCAN, st);
             switch (ix->dtype) {
@@ -1482,9 +1535,6 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
         }
         if (rc != 0) return rc;
         HIP_TRY(hipGetLastError());
-        if ((rc = launch_merge(ix->fb_partial, kTileQ, stride_q, stride_q, k, keys_out, nullptr, nullptr, st, ix->ctl->fb_list,
-                               &ix->ctl->fb_count, &ix->dstats[2])) != 0)
-            return rc;
     }
     return CODD_KNN_OK;
 }
@@ -1576,41 +1626,42 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
         return rc;
     }
 
-    // the filter passes write keys; when the caller wants only keys (the shard-local half of a sharded
-    // search) they go straight into its buffer and the unpack launch below is skipped
-    const bool keys_only = out_keys && !out_dist && !out_rows;
-    u64* keys_dst = keys_only ? out_keys : ix->keys_tmp;
+    // the filter passes write what the caller asked for — packed keys (the shard-local half of a sharded search) and / or
+    // (distance, row) — straight from finalize: no unpack launch behind them
     if (n == 0) {
         // nothing stored: all-empty result (chromadb returns {"ids": [[]], ...})
+        u64* keys_dst = out_keys ? out_keys : ix->keys_tmp;
         HIP_TRY(hipMemsetAsync(keys_dst, 0, (size_t)B * k * sizeof(u64), st));
-    } else if (use_filter) {
-        if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
-        if (!use8 && (rc = ensure_shadow(ix, st)) != 0) return rc;
-        for (int q0 = 0; q0 < B; q0 += kTileQ) {
-            const int nq = B - q0 < kTileQ ? B - q0 : kTileQ;
-            if (use8 && (rc = prep8(q0, nq)) != 0) return rc;
-            if ((rc = filter_pass(ix, ix->qn + (int64_t)q0 * ix->dpad, nq, k, row_base, keys_dst + (int64_t)q0 * k, st, fused_prep || use8, use8)) != 0)
-                return rc;
-        }
-        (use8 ? ix->watch_q8 : ix->watch_q16) += B;
-        if (ix->shadow8_enabled && !ix->watch_pending && ix->dstats) {  // one look in flight at a time
-            if (!ix->watch_host) {
-                HIP_TRY(hipHostMalloc((void**)&ix->watch_host, 4 * sizeof(unsigned long long), hipHostMallocDefault));
-                HIP_TRY(hipEventCreateWithFlags(&ix->watch_copied, hipEventDisableTiming));
-            }
-            HIP_TRY(hipMemcpyAsync(ix->watch_host, ix->dstats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipEventRecord(ix->watch_copied, st));
-            ix->watch_pending = true;
-            ix->watch_q8_sent = ix->watch_q8;
-            ix->watch_q16_sent = ix->watch_q16;
-        }
-    } else {
-        // small batches: the per-block partials merge straight into the caller's buffers
-        return exact_scan(ix, ix->qn, B, k, row_base, out_keys, out_dist, out_rows, st);
+        if (!out_dist && !out_rows) return CODD_KNN_OK;
+        return launch_merge(keys_dst, B, k, k, k, nullptr, out_dist, out_rows, st);
     }
-    if (keys_only) return CODD_KNN_OK;
-    // unpack (m == k: the merge kernel is the identity on a sorted list)
-    return launch_merge(ix->keys_tmp, B, k, k, k, out_keys, out_dist, out_rows, st);
+    if (!use_filter)  // small batches: the per-block partials merge straight into the caller's buffers
+        return exact_scan(ix, ix->qn, B, k, row_base, out_keys, out_dist, out_rows, st);
+    if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
+    if (!use8 && (rc = ensure_shadow(ix, st)) != 0) return rc;
+    for (int q0 = 0; q0 < B; q0 += kTileQ) {
+        const int nq = B - q0 < kTileQ ? B - q0 : kTileQ;
+        if (use8 && (rc = prep8(q0, nq)) != 0) return rc;
+        if ((rc = filter_pass(ix, ix->qn + (int64_t)q0 * ix->dpad, nq, k, row_base, out_keys ? out_keys + (int64_t)q0 * k : nullptr,
+                              out_dist ? out_dist + (int64_t)q0 * k : nullptr, out_rows ? out_rows + (int64_t)q0 * k : nullptr, st,
+                              fused_prep || use8, use8)) != 0)
+            return rc;
+    }
+    (use8 ? ix->watch_q8 : ix->watch_q16) += B;
+    // the index looks at its own device counters now and then (one look in flight; after its first 32 searches only every 8th:
+    // the copy is a launch of its own on the searching stream)
+    if (ix->shadow8_enabled && !ix->watch_pending && ix->dstats && (ix->stat_searches <= 32 || (ix->stat_searches & 7) == 0)) {
+        if (!ix->watch_host) {
+            HIP_TRY(hipHostMalloc((void**)&ix->watch_host, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&ix->watch_copied, hipEventDisableTiming));
+        }
+        HIP_TRY(hipMemcpyAsync(ix->watch_host, ix->dstats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(ix->watch_copied, st));
+        ix->watch_pending = true;
+        ix->watch_q8_sent = ix->watch_q8;
+        ix->watch_q16_sent = ix->watch_q16;
+    }
+    return CODD_KNN_OK;
 }
 
 }  // namespace
@@ -2105,6 +2156,11 @@ int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {
     if (strcmp(key, "resident_q") == 0) {
         if (value != 0 && value != 1) return fail(CODD_KNN_EINVAL, "resident_q must be 0 or 1%s");
         ix->resident_q = (int)value;
+        return CODD_KNN_OK;
+    }
+    if (strcmp(key, "sample_rounds8") == 0) {
+        if (value < 1 || value > 16) return fail(CODD_KNN_EINVAL, "sample_rounds8 must be in [1,16]%s");
+        ix->sample_rounds8 = (int)value;
         return CODD_KNN_OK;
     }
     if (strcmp(key, "sample_div8") == 0) {

@@ -775,7 +775,8 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
                                                        uint32_t row_base, u64* __restrict__ out_keys,
                                                        unsigned* __restrict__ fb_count, unsigned* __restrict__ fb_list,
                                                        unsigned long long* __restrict__ stats, const float* __restrict__ two_eps_q = nullptr,
-                                                       u64* __restrict__ part_keys = nullptr) {
+                                                       u64* __restrict__ part_keys = nullptr, float* __restrict__ out_dist = nullptr,
+                                                       int64_t* __restrict__ out_rows = nullptr) {
     // gridDim.y > 1: the query's hit list is shared out between gridDim.y workgroups (contiguous shares), each
     // writes its own top-k to part_keys[(q * P + p) * k ..] and a merge launch follows.  With one or a few queries
     // and thousands of survivors (the int8 filter) one workgroup per query would do all the re-scoring on one CU.
@@ -952,7 +953,17 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
         const int rank = s * kWave + lane;
-        if (rank < k) (nparts > 1 ? part_keys + ((int64_t)q * nparts + part) * k : out_keys + (int64_t)q * k)[rank] = X.v[s];
+        if (rank < k) {
+            const u64 key = X.v[s];
+            if (nparts > 1) {
+                part_keys[((int64_t)q * nparts + part) * k + rank] = key;
+            } else {
+                // the caller's (distance, row) outputs straight from here: no unpack launch behind the pass
+                if (out_keys) out_keys[(int64_t)q * k + rank] = key;
+                if (out_dist) out_dist[(int64_t)q * k + rank] = key ? 1.0f - key_score(key) : INFINITY;
+                if (out_rows) out_rows[(int64_t)q * k + rank] = key ? (int64_t)key_row(key) : (int64_t)-1;
+            }
+        }
     }
 }
 
