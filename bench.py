@@ -45,7 +45,7 @@ def parse_args():
     p.add_argument("--cpu-sample-rows", type=int, default=4_000_000)
     p.add_argument("--cpu-sample-queries", type=int, default=256)
     p.add_argument("--cpu-seconds", type=float, default=10.0)
-    p.add_argument("--hnsw-build-seconds", type=float, default=10.0, help="target build time of the HNSW comparator's sample")
+    p.add_argument("--hnsw-build-seconds", type=float, default=12.0, help="target build time of the HNSW comparator's sample")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--pipeline", type=int, default=0,
                    help="batches in flight on alternating HIP streams in the timed loop (0 = 1 on one GPU, 2 when sharded)")

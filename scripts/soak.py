@@ -31,14 +31,19 @@ while time.time() < t_end:
     ix.upsert_device(0, x.contiguous())
     for key in ("filter_min_rows", "filter_min_rows_small", "filter_min_batch"):
         ix.set_option(key, 1)
-    ix.set_option("shadow8_max_batch", int(rng.choice([8, 8, 64])))  # the int8 filter for small batches (sometimes up to 64)
+    ix.set_option("shadow8_max_batch", int(rng.choice([8, 64, 256, 256])))  # which batches take the int8 filter
+    ix.set_option("i8v2", int(rng.choice([1, 2])))                           # the tile kernel from 640 / from 384 elements on
     if rng.random() < 0.3:  # an overwrite and an append after a first search: the int8 shadow must follow
         ix.search_tensors(q[:1], 1)
         x2 = torch.randn((int(rng.integers(1, 3000)), d), generator=g, device="cuda")
         ix.upsert_device(int(rng.integers(0, n)), q[:1].contiguous())
         ix.upsert_device(n, x2)
     df, rf = ix.search_tensors(q, k)
+    if rng.random() < 0.5:  # the same index searched again right away (stale LDS / DMA / counter state must not leak)
+        q = torch.randn((B, d), generator=g, device="cuda")
+        df, rf = ix.search_tensors(q, k)
     used_filter = ix.stat("filter_passes") > 0
+    tile_passes = globals().get("tile_passes", 0) + ix.stat("i8v2_passes")
     fallbacks += ix.stat("fallback_queries")
     passes8 += ix.stat("shadow8_passes")
     ix.set_option("filter", 0)
@@ -50,5 +55,5 @@ while time.time() < t_end:
         bad = (rf != re_).any(dim=1).nonzero().flatten().tolist()[:5]
         print(f"MISMATCH n={n} d={d} dtype={dtype} B={B} k={k} kind={kind} filter={used_filter} queries={bad}", flush=True)
     ix.close()
-print(f"soak: {cases} cases, {fails} mismatches, {fallbacks} fallback queries, {passes8} int8 passes in {budget:.0f} s")
+print(f"soak: {cases} cases, {fails} mismatches, {fallbacks} fallback queries, {passes8} int8 passes ({globals().get('tile_passes', 0)} through the tile kernel) in {budget:.0f} s")
 sys.exit(1 if fails else 0)
