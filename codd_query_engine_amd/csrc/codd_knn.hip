@@ -403,8 +403,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// int8 shadow (small batches: half the bytes of the bf16 shadow).  Row r is stored as round(c_i / scale_r), scale_r =
-// max|c_i| / 127, in the same fragment order as the bf16 shadow with 16-element pieces and 128-element K-steps.  The
+// int8 shadow (half the bytes of the bf16 shadow).  Row r is stored as round(c_i / scale_b), scale_b = the largest |c_i| of
+// its 32-row block / 127 (rscale[] holds it once per row), in the same fragment order as the bf16 shadow with 16-element pieces and 128-element K-steps.  The
 // filter's error bound needs |c - c~| for the worst row: every wave folds its row's error norm into *eps_r (ordered bits).
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float butterfly_max(float v) {
@@ -424,26 +424,25 @@ __device__ __forceinline__ uint32_t quantize4(const float (&v)[4], float inv_sca
     }
     return packed;
 }
-// One workgroup quantises 16 consecutive rows (one 16-row MFMA block; 4 rows per wave, each row read once and kept in
-// registers between the max pass and the rounding), collects them in LDS and writes the block's pieces out in fragment
-// order: 16 consecutive lanes = the 16 rows of one piece column = 256 contiguous bytes (a wave per row writing its own
-// 16-byte pieces, 256 bytes apart, ran at a tenth of the HBM rate).
+// One workgroup quantises one 32-row corpus block (a wave's rows in the filter GEMMs) with ONE scale for the whole block:
+// max |c_i| over its 32 rows / 127.  (Round 1 scaled every row by its own maximum.  A scale that is uniform inside a block
+// lets the filter's epilogue test accumulators against an integer threshold before any conversion; the price, a coarser
+// grid for rows whose own maximum is smaller, is in the measured error norm *eps_r like every other quantisation error.)
+// Pass 1 finds the block maximum, pass 2 quantises the block in two halves of 16 rows (4 rows per wave), collects each half in
+// LDS and writes its pieces out in fragment order: 16 consecutive lanes = the 16 rows of one piece column = 256 contiguous
+// bytes (a wave per row writing its own 16-byte pieces, 256 bytes apart, ran at a tenth of the HBM rate).
 template <int DT>
-__global__ __launch_bounds__(256) void shadow8_from_rows_kernel(const void* __restrict__ rows_, int64_t first16, int64_t n, int dpad, int dpad8,
+__global__ __launch_bounds__(256) void shadow8_from_rows_kernel(const void* __restrict__ rows_, int64_t first32, int64_t n, int dpad, int dpad8,
                                                                 uint4* __restrict__ shadow8, float* __restrict__ rscale,
                                                                 unsigned* __restrict__ eps_r_bits) {
     constexpr int kRowDwords = 516;  // 512 + 4: sixteen rows read column-wise hit 64 different banks
     __shared__ __attribute__((aligned(16))) uint32_t tile[16 * kRowDwords];
+    __shared__ float s_max[4];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-    const int64_t row16 = first16 + (int64_t)blockIdx.x * 16;
+    const int64_t row32 = first32 + (int64_t)blockIdx.x * 32;
     const int nch = dpad >> 2, nch8 = dpad8 >> 2, nsteps8 = dpad8 >> 7;
     constexpr int kMaxIt = 8;  // <= 8 chunks of 4 elements per lane: rows of up to 2048 elements
-    float wave_err = 0.0f;     // largest error norm among this wave's rows
-    for (int rr = 0; rr < 4; ++rr) {
-        const int r = wave * 4 + rr;
-        const int64_t row = row16 + r;
-        float v[kMaxIt][4];
-        float vmax = 0.0f;
+    auto load_row = [&](int64_t row, float (&v)[kMaxIt][4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int it = 0; it < kMaxIt; ++it) {
             const int j = lane + kWave * it;
@@ -460,34 +459,57 @@ __global__ __launch_bounds__(256) void shadow8_from_rows_kernel(const void* __re
                     for (int e = 0; e < 4; ++e) v[it][e] = DT == DT_BF16 ? __uint_as_float((uint32_t)hb[e] << 16) : f16_bits_to_f32(hb[e]);
                 }
             }
+        }
+    };
+    // pass 1: the block's largest magnitude
+    float vmax = 0.0f;
+    for (int rr = 0; rr < 8; ++rr) {
+        float v[kMaxIt][4];
+        load_row(row32 + wave * 8 + rr, v);
+#pragma unroll
+        for (int it = 0; it < kMaxIt; ++it)
 #pragma unroll
             for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fabsf(v[it][e]));
-        }
-        vmax = butterfly_max(vmax);
-        const float scale = vmax > 0.0f ? vmax / 127.0f : 1.0f, inv_scale = 1.0f / scale;
-        float err2 = 0.0f;
-#pragma unroll
-        for (int it = 0; it < kMaxIt; ++it) {
-            const int j = lane + kWave * it;
-            if (j < nch8) tile[r * kRowDwords + j] = quantize4(v[it], inv_scale, scale, err2);  // (rows past n, chunks past the row: zeros)
-        }
-        err2 = butterfly_sum(err2);
-        if (row < n) {
-            if (lane == 0) rscale[row] = scale;
-            wave_err = fmaxf(wave_err, __builtin_sqrtf(err2) * 1.0001f + 1e-7f);  // inflated a little: the norm itself was accumulated in fp32
-        }
     }
-    // one device-scope atomic per workgroup at most, and only when it would raise the maximum (a single address hit by
+    vmax = butterfly_max(vmax);
+    if (lane == 0) s_max[wave] = vmax;
+    __syncthreads();
+    vmax = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    const float scale = vmax > 0.0f ? vmax / 127.0f : 1.0f, inv_scale = 1.0f / scale;
+    // pass 2: quantise (the rows come from L2 this time), 16 rows at a time
+    float wave_err = 0.0f;  // largest error norm among this wave's rows
+    for (int half = 0; half < 2; ++half) {
+        const int64_t row16 = row32 + 16 * half;
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = wave * 4 + rr;
+            const int64_t row = row16 + r;
+            float v[kMaxIt][4];
+            load_row(row, v);
+            float err2 = 0.0f;
+#pragma unroll
+            for (int it = 0; it < kMaxIt; ++it) {
+                const int j = lane + kWave * it;
+                if (j < nch8) tile[r * kRowDwords + j] = quantize4(v[it], inv_scale, scale, err2);  // (rows past n, chunks past the row: zeros)
+            }
+            err2 = butterfly_sum(err2);
+            if (row < n) {
+                if (lane == 0) rscale[row] = scale;
+                wave_err = fmaxf(wave_err, __builtin_sqrtf(err2) * 1.0001f + 1e-7f);  // inflated a little: the norm itself was accumulated in fp32
+            }
+        }
+        __syncthreads();
+        // piece (c16, r) of the half block: 16 bytes of row r at byte 16*c16
+        for (int p = (int)threadIdx.x; p < 16 * (dpad8 >> 4); p += 256) {
+            const int r = p & 15, c16 = p >> 4;
+            shadow8[codd::shadow_piece_index(row16 + r, c16, nsteps8)] = *reinterpret_cast<const uint4*>(&tile[r * kRowDwords + c16 * 4]);
+        }
+        __syncthreads();
+    }
+    // one device-scope atomic per wave at most, and only when it would raise the maximum (a single address hit by
     // one atomic per row made this kernel 10x slower than its bytes); non-negative floats order as their bits
     if (lane == 0) {
         const unsigned bits = __float_as_uint(wave_err);
         if (bits > *reinterpret_cast<volatile unsigned*>(eps_r_bits)) atomicMax(eps_r_bits, bits);
-    }
-    __syncthreads();
-    // piece (c16, r) of the block: 16 bytes of row r at byte 16*c16
-    for (int p = (int)threadIdx.x; p < 16 * (dpad8 >> 4); p += 256) {
-        const int r = p & 15, c16 = p >> 4;
-        shadow8[codd::shadow_piece_index(row16 + r, c16, nsteps8)] = *reinterpret_cast<const uint4*>(&tile[r * kRowDwords + c16 * 4]);
     }
 }
 
@@ -1303,11 +1325,12 @@ int ensure_shadow8(codd_knn_index* ix, hipStream_t st) {
     if (!ix->shadow8_ready) HIP_TRY(hipEventCreateWithFlags(&ix->shadow8_ready, hipEventDisableTiming));
     if (m > 0) {
         // an update only ever raises *eps_r (the bound stays valid for rows that have been overwritten since).
-        // Whole 16-row blocks: rows next to the dirty range are simply quantised again (same bytes).
+        // Whole 32-row blocks (one scale per block): the rows that share a block with the dirty range are quantised again,
+        // with the block's new scale.
         const int64_t last = first + m;
-        first = first / 16 * 16;
-        m = (last + 15) / 16 * 16 - first;
-        const dim3 grid((unsigned)(m / 16)), block(256);
+        first = first / 32 * 32;
+        m = (last + 31) / 32 * 32 - first;
+        const dim3 grid((unsigned)(m / 32)), block(256);
         uint4* s8 = ix->shadow8;
         switch (ix->dtype) {
             case DT_F32: hipLaunchKernelGGL(shadow8_from_rows_kernel<DT_F32>, grid, block, 0, st, ix->rows, first, n, ix->dpad, dpad8, s8, ix->rscale, ix->eps_r_bits); break;

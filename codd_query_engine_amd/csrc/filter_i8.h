@@ -30,7 +30,7 @@
 #include "filter_gemm.h"
 
 #if !CODD_EXPERIMENTS && (defined(CODD_I8_EXP_NOEPI) || defined(CODD_I8_EXP_NODMA) || defined(CODD_I8_EXP_SAMETILE) || defined(CODD_I8_EXP_NOBARRIER) || \
-                          defined(CODD_I8_EXP_NOBREAD))
+                          defined(CODD_I8_EXP_NOBREAD) || defined(CODD_I8_EXP_NOHITS))
 #error "the CODD_I8_EXP_* switches return wrong results or race: they exist only in -DCODD_EXPERIMENTS=1 builds (build_variant)"
 #endif
 
@@ -136,7 +136,11 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             const float th = thr[tid] / qscale[tid];  // the test runs on acc * rscale[row]
             // the pre-test (largest accumulator of a block pair x largest scale of the lane's rows) is only conclusive for a
             // positive threshold: thresholds <= 0 (and NaN: a zero query) always take the exact per-row test
+#ifdef CODD_I8_EXP_NOHITS
+            lds_w[(tid & 15) * 16 + (tid >> 4)] = __float_as_uint(INFINITY);  // diagnostic: no pair ever passes the pre-test
+#else
             lds_w[(tid & 15) * 16 + (tid >> 4)] = __float_as_uint(th > 0.0f ? th : -INFINITY);
+#endif
             lds_w[576 + tid] = __float_as_uint(th);
             lds_w[320 + tid] = __float_as_uint(qscale[tid]);
         }
@@ -223,8 +227,10 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
 #else
         if (MODE == MODE_FILTER) {
 #endif
-            // the lane's 16 pre-test thresholds (queries 16 qb + c) in four reads, and the largest scale among its 8 rows
-            // (NaN scales of rows past n drop out of the maximum)
+            // the lane's 16 pre-test thresholds (queries 16 qb + c) in four reads, and the scale of the wave's 32-row block: the
+            // int8 shadow is quantised with ONE scale per 32-row block (shadow8_from_rows_kernel), so every row of the lane
+            // carries the same value and the maximum below just drops the NaN scales of rows past n.  The pre-test on the
+            // pair's largest accumulator is therefore EXACT at pair level: it passes iff some value of the pair passes.
             f32x4 thp4[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) thp4[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(lds_w) + c * 16 + 4 * j);
@@ -233,9 +239,8 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             for (int qb = 0; qb < 16; ++qb) {
                 const i32x4 a0 = acc[0][qb], a1 = acc[1][qb];
                 const int m = max(max(max(a0[0], a0[1]), max(a0[2], a0[3])), max(max(a1[0], a1[1]), max(a1[2], a1[3])));
-                // no accumulator of the pair reaches the threshold when the largest one times the lane's largest scale does
-                // not (a positive accumulator times a smaller scale is smaller, rounding is monotone, a non-positive one
-                // is below a positive threshold anyway)
+                // no accumulator of the pair reaches the threshold when the largest one does not (same scale, rounding is
+                // monotone, a non-positive accumulator is below a positive threshold anyway)
                 const float thp = thp4[qb >> 2][qb & 3];
                 if (__builtin_expect(__any((float)m * rsl >= thp), 0)) {
                     const unsigned q = (unsigned)(qb * 16 + c);

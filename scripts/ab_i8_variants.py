@@ -8,9 +8,8 @@ import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANTS = {
-    "lag1": {"CODD_I8_LAG": 1},
     "noepi": {"CODD_I8_EXP_NOEPI": 1},
-    "bd3": {"CODD_I8_BDEPTH": 3},
+    "nohits": {"CODD_I8_EXP_NOHITS": 1},
 }
 
 

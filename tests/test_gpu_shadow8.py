@@ -31,9 +31,13 @@ def build8(Index, raw, dtype="f32"):
 
 
 def quantise_like_the_kernels(x, is_query):
-    """fp32 arithmetic of shadow8_from_rows_kernel / prep_queries8_kernel."""
+    """fp32 arithmetic of shadow8_from_rows_kernel / prep_queries8_kernel.  Stored rows share ONE scale per 32-row block (the
+    block's largest magnitude / 127); a query has its own."""
     x = x.astype(np.float32)
     vmax = np.abs(x).max(axis=1).astype(np.float32)
+    if not is_query:
+        pad = (-len(vmax)) % 32
+        vmax = np.repeat(np.concatenate([vmax, np.zeros(pad, np.float32)]).reshape(-1, 32).max(axis=1), 32)[: x.shape[0]]
     safe = np.where(vmax > 0, vmax, np.float32(1.0)).astype(np.float32)
     if is_query:
         scale = np.where(vmax > 0, vmax / np.float32(127.0), np.float32(0.0)).astype(np.float32)
