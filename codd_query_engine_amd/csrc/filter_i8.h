@@ -30,7 +30,7 @@
 #include "filter_gemm.h"
 
 #if !CODD_EXPERIMENTS && (defined(CODD_I8_EXP_NOEPI) || defined(CODD_I8_EXP_NODMA) || defined(CODD_I8_EXP_SAMETILE) || defined(CODD_I8_EXP_NOBARRIER) || \
-                          defined(CODD_I8_EXP_NOBREAD) || defined(CODD_I8_EXP_NOHITS))
+                          defined(CODD_I8_EXP_NOBREAD) || defined(CODD_I8_EXP_NOHITS) || defined(CODD_I8_EXP_NOAPPEND) || defined(CODD_I8_EXP_NOFLUSH) || defined(CODD_I8_EXP_NOGLOBAL))
 #error "the CODD_I8_EXP_* switches return wrong results or race: they exist only in -DCODD_EXPERIMENTS=1 builds (build_variant)"
 #endif
 
@@ -252,7 +252,15 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                         v[i] = (float)(i < 4 ? a0[i] : a1[i - 4]) * (i < 4 ? rsc0[i] : rsc1[i - 4]);  // the first-generation kernel's expression
                         hit[i] = v[i] >= th;
                     }
+#ifdef CODD_I8_EXP_NOAPPEND
+                    {   // diagnostic: the per-value test runs, nothing is appended
+                        const int anyhit = __any(hit[0] | hit[1] | hit[2] | hit[3] | hit[4] | hit[5] | hit[6] | hit[7]);
+                        asm volatile("" ::"s"(anyhit));
+                    }
+                    if (false) {
+#else
                     if (__any(hit[0] | hit[1] | hit[2] | hit[3] | hit[4] | hit[5] | hit[6] | hit[7])) {
+#endif
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             if (hit[i]) {
@@ -261,7 +269,9 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                                     lds_hits[slot * 3 + 0] = __float_as_uint(v[i]);   // (the query's scale is applied by the flush)
                                     lds_hits[slot * 3 + 1] = row0 + (unsigned)(16 * (i >> 2) + (i & 3));
                                     lds_hits[slot * 3 + 2] = q;
-                                } else {
+                                }
+#ifndef CODD_I8_EXP_NOGLOBAL  // (diagnostic: hits past a full list are dropped)
+                                else {
                                     // workgroup list full (a dense cluster many queries point at, more hits inside one tile
                                     // than the list holds): straight to the query's global list.  Slow (a returning global
                                     // atomic per hit) but complete: the query keeps its candidates and needs no fallback.
@@ -269,6 +279,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                                     if (gslot < (unsigned)cap_q)
                                         hits[(int64_t)q * cap_q + gslot] = make_key(v[i] * __uint_as_float(lds_w[320 + q]), row0 + (unsigned)(16 * (i >> 2) + (i & 3)));
                                 }
+#endif
                             }
                         }
                     }
@@ -461,7 +472,9 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         const unsigned cnt = lds_w[256];
         if (cnt > (unsigned)kHitCap && tid == 0) atomicOr(&flags[FLAG_WG_OVERFLOW], 1u);  // statistics only
         __syncthreads();  // everyone has read cnt (lds_w[0..255] is about to be reused as the flush's scratch)
+#ifndef CODD_I8_EXP_NOFLUSH  // (diagnostic: the hits of the last tiles are dropped)
         flush_hits_binned(lds_hits, cnt < (unsigned)kHitCap ? cnt : (unsigned)kHitCap, tid, lds_w, hits, hit_cnt, cap_q, reinterpret_cast<const float*>(lds_w + 320));
+#endif
     }
 }
 

@@ -10,6 +10,9 @@ sys.path.insert(0, ROOT)
 VARIANTS = {
     "noepi": {"CODD_I8_EXP_NOEPI": 1},
     "nohits": {"CODD_I8_EXP_NOHITS": 1},
+    "noappend": {"CODD_I8_EXP_NOAPPEND": 1},
+    "noflush": {"CODD_I8_EXP_NOFLUSH": 1},
+    "noglobal": {"CODD_I8_EXP_NOGLOBAL": 1},
 }
 
 
@@ -26,7 +29,7 @@ if sys.argv[1] == "build":
     print("built", list(VARIANTS))
 else:
     rows = sys.argv[2] if len(sys.argv) > 2 else "4000000"
-    for name in ["default"] + list(VARIANTS):
+    for name in ["default"] + [v for v in VARIANTS if len(sys.argv) < 4 or v in sys.argv[3:]]:
         env = dict(os.environ)
         if name != "default":
             if not os.path.exists(lib(name)):

@@ -20,9 +20,9 @@ for centres, noise in ((4096, 0.5), (4096, 0.2), (256, 0.3), (64, 0.1)):
     which = torch.randint(0, centres, (B,), generator=g, device="cuda")
     q = c[which] + noise * torch.randn((B, d), generator=g, device="cuda") / d ** 0.5
     ix.set_option("shadow8", int(os.environ.get("CODD_SHADOW8", "1")))
-    for _ in range(2):
+    for _ in range(4):  # (the engine reads its counters back asynchronously: let it settle on a filter, and build the lazy shadows, before timing)
         ix.search_tensors(q, k)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
     h0, s0, f0 = ix.stat("filter_hits"), ix.stat("filter_survivors"), ix.stat("fallback_queries")
     t0 = time.perf_counter()
     for _ in range(5):
