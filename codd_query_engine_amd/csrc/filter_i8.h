@@ -286,22 +286,40 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                 }
             }
         } else {
+            // best (score, row) of the wave's 32 rows per query, folded into the tile's keys in LDS.  The 32 rows share one scale
+            // (block-scaled shadow), so the order of their scores is the order of their accumulators: (accumulator, lower row
+            // first) packs into one int — |accumulator| <= 127 * 127 * 4096 < 2^26, five bits for the row — and the fold across
+            // the lane's 8 values and the 4 lanes that hold a query is integer max + two lane swaps; one lane per query builds
+            // the key.  (INT_MIN: a row past n.)
             const bool ragged = (tile + 1) * kTileRows > n;
+            const float rsl = fmaxf(fmaxf(fmaxf(rsc0[0], rsc0[1]), fmaxf(rsc0[2], rsc0[3])), fmaxf(fmaxf(rsc1[0], rsc1[1]), fmaxf(rsc1[2], rsc1[3])));
+            // (the key is built by lanes 0..15, whose rows 0..3 of the block are valid whenever any row of it is)
+            int code[8];
 #pragma unroll
-            for (int qb = 0; qb < 16; ++qb) {
-                u64 best = 0ull;  // this lane's best (score, row) of the pair; ties -> lower row, as everywhere
+            for (int i = 0; i < 8; ++i) code[i] = 31 - (4 * lg + 16 * (i >> 2) + (i & 3));
+            const unsigned wrow0 = (unsigned)(tile * kTileRows) + (unsigned)(wave * 32);
+            auto fold = [&](auto RAGGED) __attribute__((always_inline)) {
 #pragma unroll
-                for (int rs = 0; rs < 2; ++rs)
+                for (int qb = 0; qb < 16; ++qb) {
+                    int m = INT_MIN;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const unsigned row = row0 + (unsigned)(16 * rs + r);
-                        if (!ragged || (int64_t)row < n) {
-                            const u64 key = make_key((float)acc[rs][qb][r] * (rs ? rsc1[r] : rsc0[r]), row);
-                            best = key > best ? key : best;
-                        }
+                    for (int i = 0; i < 8; ++i) {
+                        int p = (acc[i >> 2][qb][i & 3] << 5) | code[i];
+                        if (decltype(RAGGED)::value && (int64_t)(wrow0 + (unsigned)(31 - code[i])) >= n) p = INT_MIN;
+                        m = max(m, p);
                     }
-                atomicMax(reinterpret_cast<unsigned long long*>(&lds_k[qb * 16 + c]), (unsigned long long)best);
-            }
+                    const auto s16 = __builtin_amdgcn_permlane16_swap((unsigned)m, (unsigned)m, false, false);
+                    m = max((int)s16[0], (int)s16[1]);
+                    const auto s32 = __builtin_amdgcn_permlane32_swap((unsigned)m, (unsigned)m, false, false);
+                    m = max((int)s32[0], (int)s32[1]);
+                    if (lg == 0 && m != INT_MIN) {
+                        const u64 key = make_key((float)(m >> 5) * rsl, wrow0 + (unsigned)(31 - (m & 31)));
+                        atomicMax(reinterpret_cast<unsigned long long*>(&lds_k[qb * 16 + c]), (unsigned long long)key);
+                    }
+                }
+            };
+            if (ragged) fold(std::true_type{});
+            else fold(std::false_type{});
         }
         if (!(STEPS3 && !CODD_I8_LAG)) {  // (the tile-structured program starts every tile from zero accumulators instead)
 #pragma unroll
