@@ -245,44 +245,48 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                 if (__builtin_expect(__any((float)m * rsl >= thp), 0)) {
                     const unsigned q = (unsigned)(qb * 16 + c);
                     const float th = thp == -INFINITY ? __uint_as_float(lds_w[576 + q]) : thp;  // (the exact threshold when it is not positive)
-                    float v[8];
-                    bool hit[8];
+                    // Branches are what this path pays for (no prediction: every taken one refills the wave's instruction buffer,
+                    // every exec-mask test waits for the compare), so the common case — no lane holds more than one hit among
+                    // its 8 rows — runs straight-line: the per-value tests select the lane's hit and count them, one append.
+                    auto append = [&](float val, int i) __attribute__((always_inline)) {
+                        const unsigned slot = atomicAdd(&lds_w[256], 1u);
+                        const unsigned row = row0 + (unsigned)(16 * (i >> 2) + (i & 3));
+                        if (slot < (unsigned)kHitCap) {
+                            lds_hits[slot * 3 + 0] = __float_as_uint(val);   // (the query's scale is applied by the flush)
+                            lds_hits[slot * 3 + 1] = row;
+                            lds_hits[slot * 3 + 2] = q;
+                        }
+#ifndef CODD_I8_EXP_NOGLOBAL  // (diagnostic: hits past a full list are dropped)
+                        else {
+                            // workgroup list full (a dense cluster many queries point at, more hits inside one tile than the
+                            // list holds): straight to the query's global list.  Slow (a returning global atomic per hit) but
+                            // complete: the query keeps its candidates and needs no fallback.
+                            const unsigned gslot = atomicAdd(&hit_cnt[q * kHitCntStride], 1u);
+                            if (gslot < (unsigned)cap_q) hits[(int64_t)q * cap_q + gslot] = make_key(val * __uint_as_float(lds_w[320 + q]), row);
+                        }
+#endif
+                    };
+                    float v[8], sv = 0.0f;
+                    int si = -1, cnt = 0;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         v[i] = (float)(i < 4 ? a0[i] : a1[i - 4]) * (i < 4 ? rsc0[i] : rsc1[i - 4]);  // the first-generation kernel's expression
-                        hit[i] = v[i] >= th;
+                        const bool h = v[i] >= th;
+                        sv = h ? v[i] : sv;
+                        si = h ? i : si;
+                        cnt += h ? 1 : 0;
                     }
 #ifdef CODD_I8_EXP_NOAPPEND
-                    {   // diagnostic: the per-value test runs, nothing is appended
-                        const int anyhit = __any(hit[0] | hit[1] | hit[2] | hit[3] | hit[4] | hit[5] | hit[6] | hit[7]);
-                        asm volatile("" ::"s"(anyhit));
-                    }
-                    if (false) {
+                    asm volatile("" ::"v"(sv), "v"(si), "v"(cnt));  // diagnostic: the per-value test runs, nothing is appended
 #else
-                    if (__any(hit[0] | hit[1] | hit[2] | hit[3] | hit[4] | hit[5] | hit[6] | hit[7])) {
-#endif
+                    if (__builtin_expect(__any(cnt > 1), 0)) {
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            if (hit[i]) {
-                                const unsigned slot = atomicAdd(&lds_w[256], 1u);
-                                if (slot < (unsigned)kHitCap) {
-                                    lds_hits[slot * 3 + 0] = __float_as_uint(v[i]);   // (the query's scale is applied by the flush)
-                                    lds_hits[slot * 3 + 1] = row0 + (unsigned)(16 * (i >> 2) + (i & 3));
-                                    lds_hits[slot * 3 + 2] = q;
-                                }
-#ifndef CODD_I8_EXP_NOGLOBAL  // (diagnostic: hits past a full list are dropped)
-                                else {
-                                    // workgroup list full (a dense cluster many queries point at, more hits inside one tile
-                                    // than the list holds): straight to the query's global list.  Slow (a returning global
-                                    // atomic per hit) but complete: the query keeps its candidates and needs no fallback.
-                                    const unsigned gslot = atomicAdd(&hit_cnt[q * kHitCntStride], 1u);
-                                    if (gslot < (unsigned)cap_q)
-                                        hits[(int64_t)q * cap_q + gslot] = make_key(v[i] * __uint_as_float(lds_w[320 + q]), row0 + (unsigned)(16 * (i >> 2) + (i & 3)));
-                                }
-#endif
-                            }
-                        }
+                        for (int i = 0; i < 8; ++i)
+                            if (v[i] >= th) append(v[i], i);
+                    } else if (si >= 0) {
+                        append(sv, si);
                     }
+#endif
                 }
             }
         } else {
