@@ -441,60 +441,62 @@ __global__ __launch_bounds__(256) void shadow8_from_rows_kernel(const void* __re
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     const int64_t row32 = first32 + (int64_t)blockIdx.x * 32;
     const int nch = dpad >> 2, nch8 = dpad8 >> 2, nsteps8 = dpad8 >> 7;
-    constexpr int kMaxIt = 8;  // <= 8 chunks of 4 elements per lane: rows of up to 2048 elements
-    auto load_row = [&](int64_t row, float (&v)[kMaxIt][4]) __attribute__((always_inline)) {
+    const int nit = (nch8 + kWave - 1) / kWave;  // chunks of 4 elements per lane and row
+    // chunk j = lane + 64 * it of a row (zeros past the row's end and for rows past n)
+    auto load_chunk = [&](int64_t row, int it, float (&v)[4]) __attribute__((always_inline)) {
+        const int j = lane + kWave * it;
 #pragma unroll
-        for (int it = 0; it < kMaxIt; ++it) {
-            const int j = lane + kWave * it;
+        for (int e = 0; e < 4; ++e) v[e] = 0.0f;
+        if (j < nch && row < n) {
+            if (DT == DT_F32) {
+                const float4 x = reinterpret_cast<const float4*>(rows_)[row * (int64_t)nch + j];
+                v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+            } else {
+                const uint2 x = reinterpret_cast<const uint2*>(rows_)[row * (int64_t)nch + j];
+                const uint16_t hb[4] = {(uint16_t)(x.x & 0xffffu), (uint16_t)(x.x >> 16), (uint16_t)(x.y & 0xffffu), (uint16_t)(x.y >> 16)};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[it][e] = 0.0f;
-            if (j < nch && row < n) {
-                if (DT == DT_F32) {
-                    const float4 x = reinterpret_cast<const float4*>(rows_)[row * (int64_t)nch + j];
-                    v[it][0] = x.x; v[it][1] = x.y; v[it][2] = x.z; v[it][3] = x.w;
-                } else {
-                    const uint2 x = reinterpret_cast<const uint2*>(rows_)[row * (int64_t)nch + j];
-                    const uint16_t hb[4] = {(uint16_t)(x.x & 0xffffu), (uint16_t)(x.x >> 16), (uint16_t)(x.y & 0xffffu), (uint16_t)(x.y >> 16)};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[it][e] = DT == DT_BF16 ? __uint_as_float((uint32_t)hb[e] << 16) : f16_bits_to_f32(hb[e]);
-                }
+                for (int e = 0; e < 4; ++e) v[e] = DT == DT_BF16 ? __uint_as_float((uint32_t)hb[e] << 16) : f16_bits_to_f32(hb[e]);
             }
         }
     };
-    // pass 1: the block's largest magnitude
+    // pass 1: the block's largest magnitude.  Chunk-major, the wave's 8 rows inside: eight independent loads in flight per
+    // lane (row-major with one row at a time, the kernel was a chain of HBM round trips: 26 ms for 10M x 768 rows)
     float vmax = 0.0f;
-    for (int rr = 0; rr < 8; ++rr) {
-        float v[kMaxIt][4];
-        load_row(row32 + wave * 8 + rr, v);
+    for (int it = 0; it < nit; ++it) {
+        float v[8][4];
 #pragma unroll
-        for (int it = 0; it < kMaxIt; ++it)
+        for (int rr = 0; rr < 8; ++rr) load_chunk(row32 + wave * 8 + rr, it, v[rr]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fabsf(v[it][e]));
+        for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vmax = fmaxf(vmax, fabsf(v[rr][e]));
     }
     vmax = butterfly_max(vmax);
     if (lane == 0) s_max[wave] = vmax;
     __syncthreads();
     vmax = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
     const float scale = vmax > 0.0f ? vmax / 127.0f : 1.0f, inv_scale = 1.0f / scale;
-    // pass 2: quantise (the rows come from L2 this time), 16 rows at a time
+    // pass 2: quantise (the rows come from L2 this time), 16 rows at a time, 4 rows per wave
     float wave_err = 0.0f;  // largest error norm among this wave's rows
     for (int half = 0; half < 2; ++half) {
         const int64_t row16 = row32 + 16 * half;
-        for (int rr = 0; rr < 4; ++rr) {
-            const int r = wave * 4 + rr;
-            const int64_t row = row16 + r;
-            float v[kMaxIt][4];
-            load_row(row, v);
-            float err2 = 0.0f;
+        float err2[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int it = 0; it < nit; ++it) {
+            float v[4][4];
 #pragma unroll
-            for (int it = 0; it < kMaxIt; ++it) {
-                const int j = lane + kWave * it;
-                if (j < nch8) tile[r * kRowDwords + j] = quantize4(v[it], inv_scale, scale, err2);  // (rows past n, chunks past the row: zeros)
-            }
-            err2 = butterfly_sum(err2);
+            for (int rr = 0; rr < 4; ++rr) load_chunk(row16 + wave * 4 + rr, it, v[rr]);
+            const int j = lane + kWave * it;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                if (j < nch8) tile[(wave * 4 + rr) * kRowDwords + j] = quantize4(v[rr], inv_scale, scale, err2[rr]);  // (rows past n, chunks past the row: zeros)
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int64_t row = row16 + wave * 4 + rr;
+            const float e2 = butterfly_sum(err2[rr]);
             if (row < n) {
                 if (lane == 0) rscale[row] = scale;
-                wave_err = fmaxf(wave_err, __builtin_sqrtf(err2) * 1.0001f + 1e-7f);  // inflated a little: the norm itself was accumulated in fp32
+                wave_err = fmaxf(wave_err, __builtin_sqrtf(e2) * 1.0001f + 1e-7f);  // inflated a little: the norm itself was accumulated in fp32
             }
         }
         __syncthreads();
@@ -1161,10 +1163,10 @@ void launch_finalize_slots(int slots, int B, hipStream_t st, const codd_knn_inde
                            uint32_t row_base, u64* out_keys, const float* two_eps_q, int nparts, u64* part_keys, float* out_dist, int64_t* out_rows) {
     FilterCtl* c = ix->ctl;
     if (slots == 1)
-        hipLaunchKernelGGL((finalize_kernel<DT, NITER, 1>), dim3(B, nparts), dim3(256), 0, st, ix->rows, ix->dpad, qn, ix->hits, c->hit_cnt,
+        hipLaunchKernelGGL((finalize_kernel<DT, NITER, 1>), dim3(B, nparts), dim3(kFinThreads), 0, st, ix->rows, ix->dpad, qn, ix->hits, c->hit_cnt,
                            ix->hit_cap_q, c->flags, k, two_eps, row_base, out_keys, &c->fb_count, c->fb_list, ix->dstats, two_eps_q, part_keys, out_dist, out_rows);
     else
-        hipLaunchKernelGGL((finalize_kernel<DT, NITER, 2>), dim3(B, nparts), dim3(256), 0, st, ix->rows, ix->dpad, qn, ix->hits, c->hit_cnt,
+        hipLaunchKernelGGL((finalize_kernel<DT, NITER, 2>), dim3(B, nparts), dim3(kFinThreads), 0, st, ix->rows, ix->dpad, qn, ix->hits, c->hit_cnt,
                            ix->hit_cap_q, c->flags, k, two_eps, row_base, out_keys, &c->fb_count, c->fb_list, ix->dstats, two_eps_q, part_keys, out_dist, out_rows);
 }
 

@@ -767,9 +767,14 @@ __global__ __launch_bounds__(kFilterThreads, kFilterWaves == 8 ? 2 : 1) void gem
 }
 
 constexpr int kSurvChunk = 2048;  // hits examined per round; their survivors always fit the LDS list
+#ifndef CODD_FIN_WAVES
+#define CODD_FIN_WAVES 8
+#endif
+constexpr int kFinWaves = CODD_FIN_WAVES;      // waves of a finalize workgroup (one query, or one share of its hits): the kernel is a chain of
+constexpr int kFinThreads = kFinWaves * kWave; // round trips (hit list, k anchor rows, survivor rows), so a query gets as many waves as pay
 
 template <int DT, int NITER, int SLOTS>
-__global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ rows_, int dpad, const float* __restrict__ qn,
+__global__ __launch_bounds__(kFinThreads) void finalize_kernel(const void* __restrict__ rows_, int dpad, const float* __restrict__ qn,
                                                        const u64* __restrict__ hits, const unsigned* __restrict__ hit_cnt,
                                                        int cap_q, unsigned* __restrict__ flags, int k, float two_eps,
                                                        uint32_t row_base, u64* __restrict__ out_keys,
@@ -782,11 +787,11 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
     // and thousands of survivors (the int8 filter) one workgroup per query would do all the re-scoring on one CU.
     typedef RowTraits<DT> RT;
     constexpr int E = RT::E;
-    __shared__ u64 lds_list[4 * SLOTS * kWave];
+    __shared__ u64 lds_list[kFinWaves * SLOTS * kWave];
     __shared__ unsigned lds_surv[kSurvChunk];
     __shared__ unsigned lds_n;
     __shared__ float lds_lo;
-    __shared__ float lds_anchor[4];
+    __shared__ float lds_anchor[kFinWaves];
 
     const int q = blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned total = hit_cnt[q * kHitCntStride];
@@ -813,7 +818,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
     // 1. k-th largest approximate key
     WaveTopK<SLOTS> L;
     L.init();
-    for (unsigned i0 = wave * kWave; i0 < total; i0 += 256) {
+    for (unsigned i0 = wave * kWave; i0 < total; i0 += kFinThreads) {
         const unsigned i = i0 + lane;
         L.offer_lanes(i < total ? my[i] : 0ull, k, lane);
     }
@@ -821,7 +826,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
     for (int s = 0; s < SLOTS; ++s) lds_list[(wave * SLOTS + s) * kWave + lane] = L.v[s];
     __syncthreads();
     if (wave == 0) {
-        for (int wv = 1; wv < 4; ++wv)
+        for (int wv = 1; wv < kFinWaves; ++wv)
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
                 u64 cand = lds_list[(wv * SLOTS + s) * kWave + lane];
@@ -871,7 +876,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
     {
         const unsigned nk = lds_n;
         float worst = INFINITY;
-        for (unsigned j = wave * 4; j < nk; j += 16) {
+        for (unsigned j = wave * 4; j < nk; j += 4 * kFinWaves) {
             unsigned rowid[4];
             float sc[4];
 #pragma unroll
@@ -885,7 +890,9 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
         __syncthreads();
         if (tid == 0) {
             const float eps1 = 0.5f * (two_eps_q ? two_eps_q[blockIdx.x] : two_eps);
-            const float l4 = fminf(fminf(lds_anchor[0], lds_anchor[1]), fminf(lds_anchor[2], lds_anchor[3]));
+            float l4 = lds_anchor[0];
+#pragma unroll
+            for (int wv = 1; wv < kFinWaves; ++wv) l4 = fminf(l4, lds_anchor[wv]);
             lds_lo = nk ? l4 - eps1 : -INFINITY;
         }
         __syncthreads();
@@ -904,7 +911,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
         if (tid == 0) lds_n = 0u;
         __syncthreads();
         const unsigned b1 = b0 + kSurvChunk < my_hi ? b0 + kSurvChunk : my_hi;
-        for (unsigned i = b0 + tid; i < b1; i += 256) {
+        for (unsigned i = b0 + tid; i < b1; i += kFinThreads) {
             const u64 key = my[i];
             if (key_score(key) >= lo) lds_surv[atomicAdd(&lds_n, 1u)] = key_row(key);
         }
@@ -913,7 +920,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
         survivors += ns;
         // eight rows per wave step: two independent groups of four, so that both groups' row reads are in flight
         // before the first is consumed (the loop is a chain of HBM round trips otherwise)
-        for (unsigned j0 = wave * 8; j0 < ns; j0 += 32) {
+        for (unsigned j0 = wave * 8; j0 < ns; j0 += 8 * kFinWaves) {
             unsigned rowid8[2][4];
             float sc8[2][4];
 #pragma unroll
@@ -938,12 +945,12 @@ __global__ __launch_bounds__(256) void finalize_kernel(const void* __restrict__ 
         atomicAdd(&stats[1], (unsigned long long)survivors);
     }
 
-    // 4. merge the four wave lists
+    // 4. merge the waves' lists
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) lds_list[(wave * SLOTS + s) * kWave + lane] = X.v[s];
     __syncthreads();
     if (wave != 0) return;
-    for (int wv = 1; wv < 4; ++wv)
+    for (int wv = 1; wv < kFinWaves; ++wv)
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             u64 cand = lds_list[(wv * SLOTS + s) * kWave + lane];

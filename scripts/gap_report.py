@@ -24,7 +24,7 @@ def main():
             for r in csv.DictReader(fh):
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    must = sys.argv[3] if len(sys.argv) > 3 else "gemm_filter_kernel<0, 8, 1>"
+    must = sys.argv[3] if len(sys.argv) > 3 else "i8_tile_kernel<0"
     starts = [i for i, r in enumerate(rows) if anchor in r[2]]
     starts = [s for j, s in enumerate(starts[:-1]) if any(must in r[2] for r in rows[s:starts[j + 1]])]
     if len(starts) < 10:
