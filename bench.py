@@ -411,7 +411,11 @@ def main():
             # launch) against the dense matrix peak of its operand type (MI355X_MICROARCH.md: bf16 2.5 PFLOP/s, i8 2x that)
             "matrix_side": ({"achieved": 2.0 * B * n_local * d / avg_launch_s / 1e12, "peak": 5000.0 if int8_batch else 2500.0,
                              "unit": "TOP/s" if int8_batch else "TFLOP/s",
-                             "frac": 2.0 * B * n_local * d / avg_launch_s / 1e12 / (5000.0 if int8_batch else 2500.0)}
+                             "frac": 2.0 * B * n_local * d / avg_launch_s / 1e12 / (5000.0 if int8_batch else 2500.0),
+                             # what the matrix pipe alone sustains under the chip's power limit on operand bytes like these
+                             # (a replayed constant, not measured in this run: profiles/r2/mfma_rate_micro.txt)
+                             **({"sustained_peak_measured": 4200.0, "sustained_peak_source": "profiles/r2/mfma_rate_micro.txt (int8 MFMA, Gaussian operand bytes, registers only)"}
+                                if int8_batch else {})}
                             if dom == "filter" and avg_launch_s else None),
         },
         "filter_stats": filter_stats,

@@ -187,7 +187,10 @@ int codd_knn_ivf_search(codd_knn_index* index, const float* dev_queries, int B, 
  *            badly — error norm above 0.04 — keeps the bf16 filter; so does, for the next
  *            "shadow8_cooldown" (256) searches, an index whose int8 passes leave more than
  *            "shadow8_max_surv" (4000) survivors per query or send queries to the fallback: dense
- *            clusters — unless the bf16 passes are seen to leave just as many), "sample_div8" (20),
+ *            clusters — unless the bf16 passes are seen to leave just as many), "sample_div8" (20:
+ *            the int8 filter's thresholds come from a sample of 1/20 of the row tiles) and
+ *            "sample_rounds8" (3: ... of at least that many tiles per compute unit for batches of
+ *            more than 32 queries, up to a quarter of the corpus; performance only),
  *            "resident_q" (1: rows of <= 512 int8 elements keep the query block in LDS for the
  *            whole launch), "i8v2" (1: batches of 129..256 queries on rows of more than 512
  *            elements take the second-generation int8 kernel, csrc/filter_i8.h; 2: from 384
