@@ -9,13 +9,22 @@ from codd_query_engine_amd.knn_index import DeviceKnnIndex
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+tile_only = len(sys.argv) > 3 and sys.argv[3] == "tile"  # shapes that take i8_tile_kernel only (129..256 queries, rows of >= 384 elements)
 t_end, cases, fails, fallbacks, passes8 = time.time() + budget, 0, 0, 0, 0
+t_note = time.time() + 60
 while time.time() < t_end:
+    if time.time() > t_note:  # (a silent run looks hung to the job runner)
+        print(f"... {cases} cases, {fails} mismatches so far", flush=True)
+        t_note = time.time() + 60
     d = int(rng.choice([64, 128, 192, 256, 320, 384, 512, 768, 1024]))
     dtype = str(rng.choice(["f32", "bf16", "f16"]))
     n = int(rng.integers(6_000, 250_000))
     B = int(rng.choice([1, 2, 7, 8, 9, 31, 32, 33, 64, 100, 128, 129, 255, 256, 257, 300]))
     k = int(rng.choice([1, 5, 10, 10, 10, 33, 64, 65, 100]))
+    if tile_only:
+        d = int(rng.choice([384, 512, 640, 768, 768, 1000, 1024]))
+        B = int(rng.integers(129, 257))
+        n = int(rng.integers(6_000, 400_000))
     kind = str(rng.choice(["random", "clustered", "dupes"]))
     g = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
     x = torch.randn((n, d), generator=g, device="cuda")
@@ -31,8 +40,10 @@ while time.time() < t_end:
     ix.upsert_device(0, x.contiguous())
     for key in ("filter_min_rows", "filter_min_rows_small", "filter_min_batch"):
         ix.set_option(key, 1)
-    ix.set_option("shadow8_max_batch", int(rng.choice([8, 64, 256, 256])))  # which batches take the int8 filter
-    ix.set_option("i8v2", int(rng.choice([1, 2])))                           # the tile kernel from 640 / from 384 elements on
+    ix.set_option("shadow8_max_batch", 256 if tile_only else int(rng.choice([8, 64, 256, 256])))  # which batches take the int8 filter
+    ix.set_option("i8v2", 2 if tile_only else int(rng.choice([1, 2])))       # the tile kernel from 640 / from 384 elements on
+    if tile_only:
+        ix.set_option("shadow8_cooldown", 0)
     if rng.random() < 0.3:  # an overwrite and an append after a first search: the int8 shadow must follow
         ix.search_tensors(q[:1], 1)
         x2 = torch.randn((int(rng.integers(1, 3000)), d), generator=g, device="cuda")
