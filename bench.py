@@ -47,6 +47,11 @@ def parse_args():
     p.add_argument("--cpu-seconds", type=float, default=10.0)
     p.add_argument("--hnsw-build-seconds", type=float, default=12.0, help="target build time of the HNSW comparator's sample")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--corpus", default="isotropic", choices=["isotropic", "clustered"],
+                   help="isotropic: seeded randn rows (the headline workload); clustered: unit centres + noise, queries drawn the "
+                        "same way (what embedding corpora look like: dense neighbourhoods near the top of the score distribution)")
+    p.add_argument("--centres", type=int, default=4096)
+    p.add_argument("--noise", type=float, default=0.5, help="clustered: rows = centre + noise * randn / sqrt(dim)")
     p.add_argument("--pipeline", type=int, default=0,
                    help="batches in flight on alternating HIP streams in the timed loop (0 = 1 on one GPU, 2 when sharded)")
     p.add_argument("--force-dist", action="store_true",
@@ -58,8 +63,22 @@ def planted_row(b: int, j: int, n_total: int) -> int:
     return (b * 1_234_567 + j * 99_991 + 17) % n_total
 
 
-def build_shard(ix, torch, lo, hi, n_total, dim, queries, n_planted_q, k, device):
-    """Fill rows [lo,hi) of the GLOBAL corpus: chunk c (rows [c*CH,(c+1)*CH)) is randn with seed
+def cluster_centres(torch, args, device):
+    g = torch.Generator(device=device).manual_seed(7)
+    return torch.nn.functional.normalize(torch.randn((args.centres, args.dim), generator=g, device=device), dim=1)
+
+
+def draw(torch, n, dim, g, device, centres=None, noise=0.0):
+    """n synthetic vectors from generator g: randn, or (clustered) a random centre + noise * randn / sqrt(dim)."""
+    x = torch.randn((n, dim), generator=g, device=device, dtype=torch.float32)
+    if centres is None:
+        return x
+    which = torch.randint(0, centres.shape[0], (n,), generator=g, device=device)
+    return centres[which] + (noise / dim ** 0.5) * x
+
+
+def build_shard(ix, torch, lo, hi, n_total, dim, queries, n_planted_q, k, device, centres=None, spread=0.0):
+    """Fill rows [lo,hi) of the GLOBAL corpus: chunk c (rows [c*CH,(c+1)*CH)) is drawn with seed
     1234+c, so the corpus is identical for every rank count; then the planted near-duplicates."""
     ix.reserve(max(hi - lo, 1))
     c0, c1 = lo // CHUNK_ROWS, (max(hi, 1) - 1) // CHUNK_ROWS
@@ -68,7 +87,7 @@ def build_shard(ix, torch, lo, hi, n_total, dim, queries, n_planted_q, k, device
         if b <= lo or a >= hi:
             continue
         g = torch.Generator(device=device).manual_seed(1234 + c)
-        x = torch.randn((b - a, dim), generator=g, device=device, dtype=torch.float32)
+        x = draw(torch, b - a, dim, g, device, centres, spread)
         s, e = max(a, lo), min(b, hi)
         ix.upsert_device(s - lo, x[s - a : e - a].contiguous(), normalize=True)
         torch.cuda.synchronize()
@@ -240,17 +259,18 @@ def main():
 
     N, d, B, k = args.rows, args.dim, args.batch, args.k
     lo, hi = shard_bounds(N, world, rank)
-    queries = torch.randn((B, d), generator=torch.Generator(device=device).manual_seed(4321), device=device)
+    centres = cluster_centres(torch, args, device) if args.corpus == "clustered" else None
+    queries = draw(torch, B, d, torch.Generator(device=device).manual_seed(4321), device, centres, args.noise)
     n_planted_q = min(4, B)
     # every timed step searches its own batch (seed 4321 + i; batch 0 carries the planted neighbours): a loop over one
     # batch would re-run the same thresholds, hit counts and cache state K times
     n_batches = max(1, min(args.steps, 16))
-    batches = [queries] + [torch.randn((B, d), generator=torch.Generator(device=device).manual_seed(4321 + i), device=device)
+    batches = [queries] + [draw(torch, B, d, torch.Generator(device=device).manual_seed(4321 + i), device, centres, args.noise)
                            for i in range(1, n_batches)]
 
     t_build = time.perf_counter()
     ix = DeviceKnnIndex(d, args.dtype, str(device))
-    build_shard(ix, torch, lo, hi, N, d, queries, n_planted_q, k, device)
+    build_shard(ix, torch, lo, hi, N, d, queries, n_planted_q, k, device, centres, args.noise)
     t_build = time.perf_counter() - t_build
     searcher = ShardedSearcher(ix, row_base=lo, always_gather=args.force_dist) if use_dist else None
 
@@ -381,7 +401,8 @@ def main():
         "dtype": args.dtype,
         "data": "synthetic",
         "config": {
-            "workload": f"{N} x {d} {args.dtype} corpus, batch={B} queries, top-{k}, exact cosine (BASELINE configs[2])",
+            "workload": f"{N} x {d} {args.dtype} corpus, batch={B} queries, top-{k}, exact cosine (BASELINE configs[2])"
+                        + (f"; CLUSTERED rows and queries ({args.centres} unit centres + {args.noise} * randn / sqrt(d)): not the headline workload" if centres is not None else ""),
             "rows": N, "dim": d, "batch": B, "k": k,
             "parallelism": f"row-sharded x{world}, one all_gather of B*k u64 per rank" if world > 1 else "single GPU",
             "rows_per_gpu": n_local,
