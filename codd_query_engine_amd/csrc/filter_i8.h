@@ -17,10 +17,13 @@
 //     counted lgkmcnt; values flow from each wait asm to their consumers as in/out operands;
 //   * waves 4..7 (the SIMD partners of waves 0..3) can run one K-step behind (CODD_I8_LAG), and a tile's epilogue is
 //     deferred to the start of the wave's next interval;
-//   * the epilogue tests a block pair in the integer domain first — max of the 8 accumulators of (2 row blocks x 1 query
-//     block) times the largest row scale of the wave's 32 rows against the query's threshold: 7 vector instructions per
-//     pair instead of 26 — and only pairs that can hold a hit take the exact per-row test (same expression as before,
-//     so the hit lists are the same);
+//   * the epilogue tests a block pair on its largest accumulator first — max of the lane's 8 accumulators of (2 row blocks x
+//     1 query block) times the block's scale against the query's threshold: 9 vector instructions per pair instead of 26.
+//     The int8 shadow carries ONE scale per 32-row block (= per wave tile), so that pre-test is exact at pair level and only
+//     pairs that hold a hit (about one in eight) take the per-value test — same expression as the first-generation kernel,
+//     so the hit lists are the same — which runs straight-line (select + count, one append) unless a lane holds two hits;
+//   * the sample mode folds the wave's 32 rows as packed (accumulator << 5 | 31 - row) ints: integer max, two lane swaps,
+//     one (score, row) key per query and wave;
 //   * row scales reach the epilogue through LDS (one small DMA per wave and interval), not through global loads inside a
 //     conditional region;
 //   * the workgroup's hit-list bookkeeping rides on the interval barrier: no extra barriers per tile.
@@ -134,8 +137,8 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     if (MODE == MODE_FILTER) {
         if (tid < 256) {
             const float th = thr[tid] / qscale[tid];  // the test runs on acc * rscale[row]
-            // the pre-test (largest accumulator of a block pair x largest scale of the lane's rows) is only conclusive for a
-            // positive threshold: thresholds <= 0 (and NaN: a zero query) always take the exact per-row test
+            // the pre-test (largest accumulator of a block pair x the block's scale) is only conclusive for a positive
+            // threshold: thresholds <= 0 (and NaN: a zero query) always take the exact per-value test
 #ifdef CODD_I8_EXP_NOHITS
             lds_w[(tid & 15) * 16 + (tid >> 4)] = __float_as_uint(INFINITY);  // diagnostic: no pair ever passes the pre-test
 #else
