@@ -792,6 +792,7 @@ struct codd_knn_index : WorkBufs {
     int shadow8_max_batch = 256;  // batches up to this size (one query pass) take the int8 filter
     int resident_q = 1;           // rows of <= 512 int8 elements: the query block stays in LDS ("resident_q" option)
     int i8v2 = 1;                 // full query blocks on rows of > 512 elements take i8_tile_kernel (filter_i8.h); 2: from 384 elements on; 0: never
+    int i8v2_half = 1;            // ... and so do batches of 65..128 queries (its 8-query-block instantiation)
     int sample_div8 = 20;         // its thresholds come from a larger sample (the int8 slack is ~5x the bf16 one)
     int sample_rounds8 = 3;       // ... of at least this many rounds of workgroups (one tile each) when the batch has more than 32 queries
     uint4* shadow8 = nullptr;
@@ -1213,6 +1214,9 @@ int ensure_filter_workspace(codd_knn_index* ix) {
         HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_FILTER, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_FILTER)));
         HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_FILTER, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_FILTER)));
         HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_SAMPLE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_SAMPLE)));
+        HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_FILTER, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_FILTER)));
+        HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_FILTER, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_FILTER)));
+        HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_SAMPLE, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_SAMPLE)));
         attr_set.store(true, std::memory_order_release);
     }
     return CODD_KNN_OK;
@@ -1391,7 +1395,7 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     // sample: every `stride`-th tile
     const int nbq = nq <= 32 ? 1 : (nq <= 64 ? 2 : (nq <= 128 ? 4 : 8));  // 32-query blocks the GEMM multiplies
     // full query blocks: the second-generation int8 kernel (filter_i8.h); rows whose query block fits the LDS keep the resident one
-    const bool tile_v2 = use8 && nbq == 8 && ((ix->i8v2 == 1 && !resident && nsteps >= 3) || (ix->i8v2 == 2 && nsteps >= 3));
+    const bool tile_v2 = use8 && (nbq == 8 || (nbq == 4 && ix->i8v2_half)) && ((ix->i8v2 == 1 && !resident && nsteps >= 3) || (ix->i8v2 == 2 && nsteps >= 3));
     if (tile_v2) ix->stat_i8v2_passes++;
     const int64_t ts = sample_tile_count(ix, ntiles, k, use8, nbq);
     const int64_t stride = ntiles / ts;
@@ -1413,8 +1417,12 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
                        nullptr, ix->bucket_max, nullptr, nullptr, 0, nullptr, nullptr, ix->rscale, ix->qmeta)
         if (tile_v2) {
             // (the sample pass keeps the generic program: its tile-structured instantiation spills inside the loop)
-            hipLaunchKernelGGL((i8_tile_kernel<MODE_SAMPLE, false>), g, b, i8_lds_bytes(MODE_SAMPLE), st, shadow, qfrag, n, nsteps, ts, stride, nullptr,
-                               ix->bucket_max, nullptr, nullptr, 0, nullptr, ix->rscale, ix->qmeta);
+            if (nbq == 8)
+                hipLaunchKernelGGL((i8_tile_kernel<MODE_SAMPLE, false>), g, b, i8_lds_bytes(MODE_SAMPLE), st, shadow, qfrag, n, nsteps, ts, stride, nullptr,
+                                   ix->bucket_max, nullptr, nullptr, 0, nullptr, ix->rscale, ix->qmeta);
+            else  // 65..128 queries: half the query blocks
+                hipLaunchKernelGGL((i8_tile_kernel<MODE_SAMPLE, false, 8>), g, b, i8_lds_bytes(MODE_SAMPLE), st, shadow, qfrag, n, nsteps, ts, stride, nullptr,
+                                   ix->bucket_max, nullptr, nullptr, 0, nullptr, ix->rscale, ix->qmeta);
         } else if (use8 && partial6) {  // 768 int8 elements: two of the six query slices stay in LDS
             CODD_LAUNCH_SAMPLE8P(4);
         } else if (use8 && resident) {  // the whole int8 query block fits the LDS slices: loaded once per workgroup
@@ -1482,12 +1490,17 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     hipLaunchKernelGGL((gemm_filter_kernel<MODE_FILTER, NBQ, 1, 2>), g, b, lds, st, shadow, qfrag, n, nsteps, ntiles, \
                        (int64_t)1, ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, nullptr, ix->rscale, ix->qmeta)
         if (tile_v2) {
-            if (nsteps % 3 == 0)
-                hipLaunchKernelGGL((i8_tile_kernel<MODE_FILTER, true>), g, b, i8_lds_bytes(MODE_FILTER), st, shadow, qfrag, n, nsteps, ntiles, (int64_t)1,
-                                   ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, ix->rscale, ix->qmeta);
-            else
-                hipLaunchKernelGGL((i8_tile_kernel<MODE_FILTER, false>), g, b, i8_lds_bytes(MODE_FILTER), st, shadow, qfrag, n, nsteps, ntiles, (int64_t)1,
-                                   ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, ix->rscale, ix->qmeta);
+#define CODD_LAUNCH_TILE8(S3, NQB)                                                                                                              \
+    hipLaunchKernelGGL((i8_tile_kernel<MODE_FILTER, S3, NQB>), g, b, i8_lds_bytes(MODE_FILTER), st, shadow, qfrag, n, nsteps, ntiles, (int64_t)1, \
+                       ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, ix->rscale, ix->qmeta)
+            if (nbq == 8) {
+                if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(true, 16);
+                else CODD_LAUNCH_TILE8(false, 16);
+            } else {
+                if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(true, 8);
+                else CODD_LAUNCH_TILE8(false, 8);
+            }
+#undef CODD_LAUNCH_TILE8
         } else if (use8 && partial6) {
             CODD_LAUNCH_FILTER8P(4);
         } else if (use8 && resident) {
@@ -2176,6 +2189,11 @@ int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {
     if (strcmp(key, "i8v2") == 0) {
         if (value < 0 || value > 2) return fail(CODD_KNN_EINVAL, "i8v2 must be 0, 1 or 2%s");
         ix->i8v2 = (int)value;
+        return CODD_KNN_OK;
+    }
+    if (strcmp(key, "i8v2_half") == 0) {
+        if (value != 0 && value != 1) return fail(CODD_KNN_EINVAL, "i8v2_half must be 0 or 1%s");
+        ix->i8v2_half = (int)value;
         return CODD_KNN_OK;
     }
     if (strcmp(key, "resident_q") == 0) {

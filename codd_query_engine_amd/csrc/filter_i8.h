@@ -99,7 +99,8 @@ __device__ __forceinline__ void lgkm_wait_asm(i32x4& v) {
 }
 
 // vector-memory operations per interval, in issue order: scale DMA, kDmaPerIv slice DMA, kAPerIv corpus loads
-constexpr int kDmaPerIv = 4, kAPerIv = 4, kOpsPerIv = 1 + kDmaPerIv + kAPerIv;
+// (kDmaPerIv = NQB / 4: a slice of 16 NQB queries is NQB / 2 chunks of 1 KiB per wave pair... 2 NQB KiB in all, 8 waves)
+constexpr int kAPerIv = 4;
 // bookkeeping words behind the slices: [0..255] pre-test thresholds, transposed ([query & 15][query >> 4]); [256] hit count;
 // [320..575] query scales; [576..831] exact thresholds (thr / qscale), by query; [832..1087] scratch of the in-loop flush.
 // SAMPLE: [0..511] = 256 u64 keys.
@@ -109,14 +110,18 @@ __host__ __device__ constexpr size_t i8_lds_bytes(int mode) {
     return (size_t)4 * kI8SliceBytes + kI8Words * 4 + kI8RsBufs * kI8RsStride * 4 + (mode == MODE_FILTER ? (size_t)kHitCap * 12 : 0);
 }
 
-// STEPS3: the row has a multiple of 3 K-steps (the host picks the instantiation): tiles start at corpus-ring phase 0
-template <int MODE, bool STEPS3>
+// STEPS3: the row has a multiple of 3 K-steps (the host picks the instantiation): tiles start at corpus-ring phase 0.
+// NQB: query blocks of 16 the launch multiplies: 16 (129..256 queries) or 8 (65..128: half the MFMAs, half the slice bytes;
+// the slices keep their 32 KiB slots and the bookkeeping its 256-query layout).
+template <int MODE, bool STEPS3, int NQB = 16>
 __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict__ shadow8, const uint4* __restrict__ qfrag8, int64_t n, int nsteps,
                                                          int64_t ntiles_run, int64_t tile_stride, const float* __restrict__ thr,
                                                          u64* __restrict__ bucket_key, u64* __restrict__ hits, unsigned* __restrict__ hit_cnt,
                                                          int cap_q, unsigned* __restrict__ flags, const float* __restrict__ rscale,
                                                          const float* __restrict__ qscale) {
     static_assert(MODE == MODE_FILTER || MODE == MODE_SAMPLE, "filter and sample passes only");
+    static_assert(NQB == 16 || NQB == 8, "256 or 128 queries");
+    constexpr int kDmaPerIv = NQB / 4, kOpsPerIv = 1 + kDmaPerIv + kAPerIv;  // vector-memory operations per interval (see above)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* lds_w = reinterpret_cast<unsigned*>(smem + 4 * kI8SliceBytes);
     float* lds_rs = reinterpret_cast<float*>(lds_w + kI8Words);                  // row scales of the tiles in flight
@@ -157,11 +162,11 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     const int64_t step_bytes = 4096;                       // 4 pieces x 1 KiB: this wave's 32 rows x 128 elements
     const int64_t tile_bytes = (int64_t)8 * nsteps * step_bytes;
 
-    i32x4 acc[2][16];
+    i32x4 acc[2][NQB];
 #pragma unroll
     for (int rs = 0; rs < 2; ++rs)
 #pragma unroll
-        for (int qb = 0; qb < 16; ++qb) acc[rs][qb] = i32x4{0, 0, 0, 0};
+        for (int qb = 0; qb < NQB; ++qb) acc[rs][qb] = i32x4{0, 0, 0, 0};
 
     // ---- corpus fragments: HBM -> registers, ring of 3 K-steps, the cursor runs 2 steps ahead (1 for a lagging wave) ----
     int64_t l_u = first_u;  // run-tile ordinal of the next step to load
@@ -184,7 +189,8 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     };
 
     // ---- query slices: L2 -> LDS by LDS-DMA, slice of step t in LDS slice t & 3, requested two intervals ahead ----
-    // wave w moves the 1 KiB chunks 8j + w (j = 0..3) of a slice: 64 lanes x 16 bytes each, contiguous on both sides
+    // wave w moves the 1 KiB chunks 8j + w (j < kDmaPerIv) of a slice: 64 lanes x 16 bytes each, contiguous on both sides
+    // (pieces are ordered [query block][K half]: the first 2 NQB chunks of a 256-query slice are query blocks 0..NQB-1)
     int q_s = 0;
     auto stage_dma = [&](int slot) __attribute__((always_inline)) {
         const int soff = q_s * kI8SliceBytes + wave * 1024;
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
 #ifdef CODD_I8_EXP_NOEPI
         if (true) {
 #pragma unroll
-            for (int qb = 0; qb < 16; ++qb) { asm volatile("" ::"v"(acc[0][qb])); asm volatile("" ::"v"(acc[1][qb])); }
+            for (int qb = 0; qb < NQB; ++qb) { asm volatile("" ::"v"(acc[0][qb])); asm volatile("" ::"v"(acc[1][qb])); }
         } else if (false) {
 #else
         if (MODE == MODE_FILTER) {
@@ -234,12 +240,12 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             // int8 shadow is quantised with ONE scale per 32-row block (shadow8_from_rows_kernel), so every row of the lane
             // carries the same value and the maximum below just drops the NaN scales of rows past n.  The pre-test on the
             // pair's largest accumulator is therefore EXACT at pair level: it passes iff some value of the pair passes.
-            f32x4 thp4[4];
+            f32x4 thp4[NQB / 4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) thp4[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(lds_w) + c * 16 + 4 * j);
+            for (int j = 0; j < NQB / 4; ++j) thp4[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(lds_w) + c * 16 + 4 * j);
             const float rsl = fmaxf(fmaxf(fmaxf(rsc0[0], rsc0[1]), fmaxf(rsc0[2], rsc0[3])), fmaxf(fmaxf(rsc1[0], rsc1[1]), fmaxf(rsc1[2], rsc1[3])));
 #pragma unroll
-            for (int qb = 0; qb < 16; ++qb) {
+            for (int qb = 0; qb < NQB; ++qb) {
                 const i32x4 a0 = acc[0][qb], a1 = acc[1][qb];
                 const int m = max(max(max(a0[0], a0[1]), max(a0[2], a0[3])), max(max(a1[0], a1[1]), max(a1[2], a1[3])));
                 // no accumulator of the pair reaches the threshold when the largest one does not (same scale, rounding is
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             const unsigned wrow0 = (unsigned)(tile * kTileRows) + (unsigned)(wave * 32);
             auto fold = [&](auto RAGGED) __attribute__((always_inline)) {
 #pragma unroll
-                for (int qb = 0; qb < 16; ++qb) {
+                for (int qb = 0; qb < NQB; ++qb) {
                     int m = INT_MIN;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
@@ -332,11 +338,11 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
 #pragma unroll
             for (int rs = 0; rs < 2; ++rs)
 #pragma unroll
-                for (int qb = 0; qb < 16; ++qb) acc[rs][qb] = i32x4{0, 0, 0, 0};
+                for (int qb = 0; qb < NQB; ++qb) acc[rs][qb] = i32x4{0, 0, 0, 0};
         }
     };
 
-    // MFMAs of one K-step: corpus fragments in ring slot SLOT, query slice at LDS byte address qaddr (+ lane * 16).  32
+    // MFMAs of one K-step: corpus fragments in ring slot SLOT, query slice at LDS byte address qaddr (+ lane * 16).  2 NQB
     // groups (K half ks, query block qb) of 2 MFMAs; the fragment of group g + kBD is requested when group g has
     // consumed its register set.  Before group g the reads of groups g+1 .. min(31, g + kBD - 1) are the only younger
     // LGKM operations and LDS returns in order, hence lgkmcnt(that many).  FIRST: the first K-step of a tile starts its
@@ -345,22 +351,23 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         constexpr int slot = decltype(SLOT)::value;
         constexpr bool first = decltype(FIRST)::value;
         i32x4 b[kBD];
+        constexpr int kGroups = 2 * NQB;  // (K half, query block) groups of 2 MFMAs per K-step
         static_for<kBD>([&](auto G_) __attribute__((always_inline)) {
             constexpr int g = decltype(G_)::value;
-            lds_read_b128_asm<(((g & 15) * 2) + (g >> 4)) * 1024>(b[g], qaddr);
+            lds_read_b128_asm<(((g % NQB) * 2) + (g / NQB)) * 1024>(b[g], qaddr);
         });
-        static_for<32>([&](auto G_) __attribute__((always_inline)) {
-            constexpr int g = decltype(G_)::value, ks = g >> 4, qb = g & 15;
-            constexpr int younger = (g + kBD - 1 < 31 ? g + kBD - 1 : 31) - g;
+        static_for<kGroups>([&](auto G_) __attribute__((always_inline)) {
+            constexpr int g = decltype(G_)::value, ks = g / NQB, qb = g % NQB;
+            constexpr int younger = (g + kBD - 1 < kGroups - 1 ? g + kBD - 1 : kGroups - 1) - g;
             lgkm_wait_asm<younger>(b[g % kBD]);
             const i32x4 a0 = __builtin_bit_cast(i32x4, ring[slot][0 * 2 + ks]);
             const i32x4 a1 = __builtin_bit_cast(i32x4, ring[slot][1 * 2 + ks]);
             const i32x4 zero = {0, 0, 0, 0};
             acc[0][qb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b[g % kBD], first && ks == 0 ? zero : acc[0][qb], 0, 0, 0);
             acc[1][qb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b[g % kBD], first && ks == 0 ? zero : acc[1][qb], 0, 0, 0);
-            if constexpr (g + kBD < 32) {
+            if constexpr (g + kBD < kGroups) {
                 constexpr int g2 = g + kBD;
-                lds_read_b128_asm<(((g2 & 15) * 2) + (g2 >> 4)) * 1024>(b[g % kBD], qaddr);
+                lds_read_b128_asm<(((g2 % NQB) * 2) + (g2 / NQB)) * 1024>(b[g % kBD], qaddr);
             }
             __builtin_amdgcn_sched_barrier(0);
         });

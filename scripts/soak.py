@@ -9,7 +9,7 @@ from codd_query_engine_amd.knn_index import DeviceKnnIndex
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 90.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-tile_only = len(sys.argv) > 3 and sys.argv[3] == "tile"  # shapes that take i8_tile_kernel only (129..256 queries, rows of >= 384 elements)
+tile_only = len(sys.argv) > 3 and sys.argv[3] == "tile"  # shapes that take i8_tile_kernel only (65..256 queries, rows of >= 384 elements)
 t_end, cases, fails, fallbacks, passes8 = time.time() + budget, 0, 0, 0, 0
 t_note = time.time() + 60
 while time.time() < t_end:
@@ -23,7 +23,7 @@ while time.time() < t_end:
     k = int(rng.choice([1, 5, 10, 10, 10, 33, 64, 65, 100]))
     if tile_only:
         d = int(rng.choice([384, 512, 640, 768, 768, 1000, 1024]))
-        B = int(rng.integers(129, 257))
+        B = int(rng.integers(65, 257))
         n = int(rng.integers(6_000, 400_000))
     kind = str(rng.choice(["random", "clustered", "dupes"]))
     g = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))

@@ -1,4 +1,5 @@
-"""i8_tile_kernel (csrc/filter_i8.h): the int8 filter GEMM of full query blocks (129..256 queries, rows of more than 512
+"""i8_tile_kernel (csrc/filter_i8.h): the int8 filter GEMM of full query blocks (129..256 queries, and 65..128 through its
+8-query-block instantiation; rows of more than 512
 elements; from 384 elements on with the option i8v2 = 2).  Hand-ordered LDS-DMA staging, a lagging half of the
 workgroup, deferred epilogues with an integer pre-test: all of it may only change SPEED.  Ids and distances must equal
 the oracle's bit for bit, and the candidate lists must be the ones the first-generation kernel writes."""
@@ -40,6 +41,11 @@ def oracle_answer(raw, q, k, dtype):
     "n,d,B,k,dtype,i8v2",
     [
         (70_000, 768, 256, 10, "f32", 1),    # the headline shape, scaled down: 274 tiles, 6 K-steps
+        (70_000, 768, 128, 10, "f32", 1),    # 65..128 queries: the 8-query-block instantiation (half the slice DMA per interval)
+        (70_001, 768, 65, 10, "f32", 1),     # ... its smallest batch, ragged last tile
+        (66_000, 640, 100, 100, "f32", 1),   # ... 5 K-steps (generic loop), k = 100
+        (30_000, 1024, 128, 10, "bf16", 1),  # ... 8 K-steps
+        (50_000, 384, 96, 10, "f32", 2),     # ... 3 K-steps, i8v2 = 2
         (70_001, 768, 129, 10, "f32", 1),    # ragged last tile, smallest batch that takes this kernel
         (40_000, 640, 200, 10, "f32", 1),    # 5 K-steps: tiles end at every position of the 3-interval body
         (40_000, 1024, 256, 10, "f16", 1),   # 8 K-steps (config 5's width)

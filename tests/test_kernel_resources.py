@@ -29,9 +29,9 @@ def test_hot_kernels_do_not_spill():
     # the second-generation int8 kernel (filter_i8.h): two waves per SIMD, and at most a few registers of loop invariants
     # parked in scratch around the loop (a reload INSIDE the loop would wait vmcnt(0) and drain the hand-counted prefetch)
     tile = [name for name in rows if "i8_tile_kernel" in name]
-    assert len(tile) == 3, report
+    assert len(tile) == 6, report  # filter (3-step-multiple rows / others) and sample, for 16 and for 8 query blocks
     for name in tile:
-        assert rows[name]["occ"] == 2 and rows[name]["scratch"] <= 32, f"{name}:\n{report}"
+        assert rows[name]["occ"] >= 2 and rows[name]["scratch"] <= 32, f"{name}:\n{report}"
     full = next(name for name in rows if "gemm_filter_kernel<0, 8, 0, 0>" in name)
     int8 = next(name for name in rows if "gemm_filter_kernel<0, 1, 1, 0>" in name)  # the single-query latency kernel (int8 shadow)
     assert rows[int8]["occ"] >= 2, report
