@@ -47,6 +47,8 @@ def parse_args():
     p.add_argument("--cpu-seconds", type=float, default=10.0)
     p.add_argument("--hnsw-build-seconds", type=float, default=12.0, help="target build time of the HNSW comparator's sample")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
+                   help="engine option for A/B runs (codd_knn_set_option), e.g. --set i8v2=2; recorded in the line")
     p.add_argument("--corpus", default="isotropic", choices=["isotropic", "clustered"],
                    help="isotropic: seeded randn rows (the headline workload); clustered: unit centres + noise, queries drawn the "
                         "same way (what embedding corpora look like: dense neighbourhoods near the top of the score distribution)")
@@ -272,6 +274,9 @@ def main():
     ix = DeviceKnnIndex(d, args.dtype, str(device))
     build_shard(ix, torch, lo, hi, N, d, queries, n_planted_q, k, device, centres, args.noise)
     t_build = time.perf_counter() - t_build
+    for kv in args.set:
+        key, _, val = kv.partition("=")
+        ix.set_option(key, int(val))
     searcher = ShardedSearcher(ix, row_base=lo, always_gather=args.force_dist) if use_dist else None
 
     def step(q):
@@ -407,6 +412,7 @@ def main():
             "parallelism": f"row-sharded x{world}, one all_gather of B*k u64 per rank" if world > 1 else "single GPU",
             "rows_per_gpu": n_local,
             "batches_in_flight": depth,
+            **({"engine_options": args.set} if args.set else {}),
         },
         **({"rehearsal": "all ranks on cuda:0, gloo collective: code-path check, not a measurement"} if rehearsal else {}),
         "p50_latency_ms_batch1": p50_ms,

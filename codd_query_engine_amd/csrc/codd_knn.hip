@@ -791,7 +791,8 @@ struct codd_knn_index : WorkBufs {
     int shadow8_enabled = 1;
     int shadow8_max_batch = 256;  // batches up to this size (one query pass) take the int8 filter
     int resident_q = 1;           // rows of <= 512 int8 elements: the query block stays in LDS ("resident_q" option)
-    int i8v2 = 1;                 // full query blocks on rows of > 512 elements take i8_tile_kernel (filter_i8.h); 2: from 384 elements on; 0: never
+    int i8v2 = 2;                 // batches of 65..256 queries on rows of >= 384 elements (3 K-steps) take i8_tile_kernel (filter_i8.h); 1: only rows of
+                                  // more than 512 elements (below, the first-generation kernel keeps the query block resident in LDS: 6-12 % slower); 0: never
     int i8v2_half = 1;            // ... and so do batches of 65..128 queries (its 8-query-block instantiation)
     int sample_div8 = 20;         // its thresholds come from a larger sample (the int8 slack is ~5x the bf16 one)
     int sample_rounds8 = 3;       // ... of at least this many rounds of workgroups (one tile each) when the batch has more than 32 queries

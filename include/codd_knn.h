@@ -192,9 +192,9 @@ int codd_knn_ivf_search(codd_knn_index* index, const float* dev_queries, int B, 
  *            "sample_rounds8" (3: ... of at least that many tiles per compute unit for batches of
  *            more than 32 queries, up to a quarter of the corpus; performance only),
  *            "resident_q" (1: rows of <= 512 int8 elements keep the query block in LDS for the
- *            whole launch), "i8v2" (1: batches of 129..256 queries on rows of more than 512
- *            elements take the second-generation int8 kernel, csrc/filter_i8.h; 2: from 384
- *            elements on; 0: never), "i8v2_half" (1: batches of 65..128 queries take that kernel's
+ *            whole launch), "i8v2" (2: batches of 65..256 queries on rows of 384 or
+ *            more elements take the second-generation int8 kernel, csrc/filter_i8.h; 1: only rows of
+ *            more than 512 elements; 0: never), "i8v2_half" (1: batches of 65..128 queries take that kernel's
  *            8-query-block instantiation; 0: the first-generation kernel);
  *            "profile" = N keeps N (start, stop) HIP-event pairs, one per heavy-kernel launch,
  *            recorded on the launch stream (0 = off; resets the log)
