@@ -50,6 +50,9 @@ constexpr int kI8RsStride = 272;      // floats per buffer: 256 row scales + 8 p
 #define CODD_I8_BDEPTH 4              // query-fragment register sets in flight
 #endif
 constexpr int kBD = CODD_I8_BDEPTH;
+#ifndef CODD_I8_EARLY_FRAGS
+#define CODD_I8_EARLY_FRAGS 1         // the first fragment reads of a K-step go out before the interval's DMA / corpus-load instructions (0: behind them)
+#endif
 #ifndef CODD_I8_LAG
 #define CODD_I8_LAG 0                 // 1: waves 4..7 run one K-step behind waves 0..3 (measured slower: an epilogue takes longer than the partner's MFMAs of one step, profiles/r2/i8_tile_ablation.txt)
 #endif
@@ -347,15 +350,19 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     // consumed its register set.  Before group g the reads of groups g+1 .. min(31, g + kBD - 1) are the only younger
     // LGKM operations and LDS returns in order, hence lgkmcnt(that many).  FIRST: the first K-step of a tile starts its
     // accumulators from zero (no clearing pass after the epilogue).
-    auto mfma_step = [&](auto SLOT, auto FIRST, unsigned qaddr) __attribute__((always_inline)) {
-        constexpr int slot = decltype(SLOT)::value;
-        constexpr bool first = decltype(FIRST)::value;
-        i32x4 b[kBD];
-        constexpr int kGroups = 2 * NQB;  // (K half, query block) groups of 2 MFMAs per K-step
+    // the first kBD fragment reads of a K-step: issued right behind the interval's barrier, BEFORE the interval's DMA and
+    // corpus-load instructions, so that their LDS round trip runs beside that issue work instead of after it (every wave
+    // of the workgroup is at this point at the same time: nothing else feeds the matrix pipe here)
+    auto frag_prefetch = [&](i32x4(&b)[kBD], unsigned qaddr) __attribute__((always_inline)) {
         static_for<kBD>([&](auto G_) __attribute__((always_inline)) {
             constexpr int g = decltype(G_)::value;
             lds_read_b128_asm<(((g % NQB) * 2) + (g / NQB)) * 1024>(b[g], qaddr);
         });
+    };
+    auto mfma_step = [&](auto SLOT, auto FIRST, i32x4(&b)[kBD], unsigned qaddr) __attribute__((always_inline)) {
+        constexpr int slot = decltype(SLOT)::value;
+        constexpr bool first = decltype(FIRST)::value;
+        constexpr int kGroups = 2 * NQB;  // (K half, query block) groups of 2 MFMAs per K-step
         static_for<kGroups>([&](auto G_) __attribute__((always_inline)) {
             constexpr int g = decltype(G_)::value, ks = g / NQB, qb = g % NQB;
             constexpr int younger = (g + kBD - 1 < kGroups - 1 ? g + kBD - 1 : kGroups - 1) - g;
@@ -413,15 +420,19 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                 pending = false;
             }
             __builtin_amdgcn_sched_barrier(0);
+            const unsigned qaddr = lds0 + (unsigned)(((t - LAG) & 3) * kI8SliceBytes + lane16);
+            i32x4 b[kBD];
+            if (CODD_I8_EARLY_FRAGS) frag_prefetch(b, qaddr);
+            __builtin_amdgcn_sched_barrier(0);
             rs_dma(w_u, w_ord);
 #ifndef CODD_I8_EXP_NODMA
             stage_dma((t + 2) & 3);
 #endif
-            const unsigned qaddr = lds0 + (unsigned)(((t - LAG) & 3) * kI8SliceBytes + lane16);
             load_a(ring[li]);
             i8_wait_vm<2 * kOpsPerIv>(ring[ci][0], ring[ci][1], ring[ci][2], ring[ci][3]);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_step(std::integral_constant<int, ci>{}, FIRST, qaddr);
+            if (!CODD_I8_EARLY_FRAGS) frag_prefetch(b, qaddr);
+            mfma_step(std::integral_constant<int, ci>{}, FIRST, b, qaddr);
             const int s = t - LAG;
             if (s >= 0) {
                 if (s < T && c_s == nsteps - 1) { pending = true; p_u = c_u; p_ord = c_ord; }

@@ -13,6 +13,7 @@ VARIANTS = {
     "noappend": {"CODD_I8_EXP_NOAPPEND": 1},
     "noflush": {"CODD_I8_EXP_NOFLUSH": 1},
     "noglobal": {"CODD_I8_EXP_NOGLOBAL": 1},
+    "latefrags": {"CODD_I8_EARLY_FRAGS": 0},
 }
 
 
