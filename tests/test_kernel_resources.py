@@ -26,8 +26,8 @@ def test_hot_kernels_do_not_spill():
     assert len(hot) >= 12, report
     for name in hot:
         assert rows[name]["scratch"] == 0 and rows[name]["spill"] == 0, f"{name} spills:\n{report}"
-    # the second-generation int8 kernel (filter_i8.h): two waves per SIMD, and at most a few registers of loop invariants
-    # parked in scratch around the loop (a reload INSIDE the loop would wait vmcnt(0) and drain the hand-counted prefetch)
+    # the second-generation int8 kernel (filter_i8.h): two waves per SIMD and no scratch (a reload inside the loop would wait
+    # vmcnt(0) and drain the hand-counted prefetch)
     tile = [name for name in rows if "i8_tile_kernel" in name]
     assert len(tile) == 6, report  # filter (3-step-multiple rows / others) and sample, for 16 and for 8 query blocks
     for name in tile:
