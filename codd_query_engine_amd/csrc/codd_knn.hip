@@ -1458,7 +1458,7 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
         const int nch_t = ix->dpad / elems_per_chunk(ix->dtype);
         const int niter_t = (nch_t + kWave - 1) / kWave;
 #define CODD_ANCHOR(DT, NI, SL)                                                                                                       \
-    hipLaunchKernelGGL((anchor_thr_kernel<DT, NI, SL>), dim3(kTileQ), dim3(64), 0, st, ix->bucket_max, ts, nq, k, ix->rows, ix->dpad, qn, \
+    hipLaunchKernelGGL((anchor_thr_kernel<DT, NI, SL>), dim3(kTileQ), dim3(kAnchorWaves * kWave), 0, st, ix->bucket_max, ts, nq, k, ix->rows, ix->dpad, qn, \
                        eps, slack_q, ix->thr)
 #define CODD_ANCHOR_NI(DT, SL)                                \
     switch (niter_t) {                                         \
