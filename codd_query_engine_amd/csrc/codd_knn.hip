@@ -1218,6 +1218,11 @@ int ensure_filter_workspace(codd_knn_index* ix) {
         HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_FILTER, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_FILTER)));
         HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_FILTER, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_FILTER)));
         HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_SAMPLE, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_SAMPLE)));
+        const void* res_fns[] = {(const void*)&i8_tile_kernel<MODE_FILTER, true, 16, true>, (const void*)&i8_tile_kernel<MODE_FILTER, false, 16, true>,
+                                 (const void*)&i8_tile_kernel<MODE_FILTER, true, 8, true>, (const void*)&i8_tile_kernel<MODE_FILTER, false, 8, true>};
+        for (const void* fn : res_fns) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_FILTER)));
+        HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_SAMPLE, false, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_SAMPLE)));
+        HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_SAMPLE, false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_SAMPLE)));
         attr_set.store(true, std::memory_order_release);
     }
     return CODD_KNN_OK;
@@ -1418,12 +1423,18 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
                        nullptr, ix->bucket_max, nullptr, nullptr, 0, nullptr, nullptr, ix->rscale, ix->qmeta)
         if (tile_v2) {
             // (the sample pass keeps the generic program: its tile-structured instantiation spills inside the loop)
-            if (nbq == 8)
-                hipLaunchKernelGGL((i8_tile_kernel<MODE_SAMPLE, false>), g, b, i8_lds_bytes(MODE_SAMPLE), st, shadow, qfrag, n, nsteps, ts, stride, nullptr,
-                                   ix->bucket_max, nullptr, nullptr, 0, nullptr, ix->rscale, ix->qmeta);
-            else  // 65..128 queries: half the query blocks
-                hipLaunchKernelGGL((i8_tile_kernel<MODE_SAMPLE, false, 8>), g, b, i8_lds_bytes(MODE_SAMPLE), st, shadow, qfrag, n, nsteps, ts, stride, nullptr,
-                                   ix->bucket_max, nullptr, nullptr, 0, nullptr, ix->rscale, ix->qmeta);
+#define CODD_LAUNCH_TILE8_SAMPLE(NQB, RES)                                                                                                    \
+    hipLaunchKernelGGL((i8_tile_kernel<MODE_SAMPLE, false, NQB, RES>), g, b, i8_lds_bytes(MODE_SAMPLE), st, shadow, qfrag, n, nsteps, ts, stride, \
+                       nullptr, ix->bucket_max, nullptr, nullptr, 0, nullptr, ix->rscale, ix->qmeta)
+            const bool res = nsteps <= 4 && ix->resident_q;  // the query block fits the four LDS slices: loaded once per workgroup
+            if (nbq == 8) {
+                if (res) CODD_LAUNCH_TILE8_SAMPLE(16, true);
+                else CODD_LAUNCH_TILE8_SAMPLE(16, false);
+            } else {  // 65..128 queries: half the query blocks
+                if (res) CODD_LAUNCH_TILE8_SAMPLE(8, true);
+                else CODD_LAUNCH_TILE8_SAMPLE(8, false);
+            }
+#undef CODD_LAUNCH_TILE8_SAMPLE
         } else if (use8 && partial6) {  // 768 int8 elements: two of the six query slices stay in LDS
             CODD_LAUNCH_SAMPLE8P(4);
         } else if (use8 && resident) {  // the whole int8 query block fits the LDS slices: loaded once per workgroup
@@ -1491,15 +1502,16 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     hipLaunchKernelGGL((gemm_filter_kernel<MODE_FILTER, NBQ, 1, 2>), g, b, lds, st, shadow, qfrag, n, nsteps, ntiles, \
                        (int64_t)1, ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, nullptr, ix->rscale, ix->qmeta)
         if (tile_v2) {
-#define CODD_LAUNCH_TILE8(S3, NQB)                                                                                                              \
-    hipLaunchKernelGGL((i8_tile_kernel<MODE_FILTER, S3, NQB>), g, b, i8_lds_bytes(MODE_FILTER), st, shadow, qfrag, n, nsteps, ntiles, (int64_t)1, \
+#define CODD_LAUNCH_TILE8(S3, NQB, RES)                                                                                                              \
+    hipLaunchKernelGGL((i8_tile_kernel<MODE_FILTER, S3, NQB, RES>), g, b, i8_lds_bytes(MODE_FILTER), st, shadow, qfrag, n, nsteps, ntiles, (int64_t)1, \
                        ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, ix->rscale, ix->qmeta)
+            const bool res = nsteps <= 4 && ix->resident_q;
             if (nbq == 8) {
-                if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(true, 16);
-                else CODD_LAUNCH_TILE8(false, 16);
+                if (res) { if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(true, 16, true); else CODD_LAUNCH_TILE8(false, 16, true); }
+                else { if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(true, 16, false); else CODD_LAUNCH_TILE8(false, 16, false); }
             } else {
-                if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(true, 8);
-                else CODD_LAUNCH_TILE8(false, 8);
+                if (res) { if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(true, 8, true); else CODD_LAUNCH_TILE8(false, 8, true); }
+                else { if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(true, 8, false); else CODD_LAUNCH_TILE8(false, 8, false); }
             }
 #undef CODD_LAUNCH_TILE8
         } else if (use8 && partial6) {

@@ -116,7 +116,9 @@ __host__ __device__ constexpr size_t i8_lds_bytes(int mode) {
 // STEPS3: the row has a multiple of 3 K-steps (the host picks the instantiation): tiles start at corpus-ring phase 0.
 // NQB: query blocks of 16 the launch multiplies: 16 (129..256 queries) or 8 (65..128: half the MFMAs, half the slice bytes;
 // the slices keep their 32 KiB slots and the bookkeeping its 256-query layout).
-template <int MODE, bool STEPS3, int NQB = 16>
+// RES: rows of <= 4 K-steps (512 elements): the whole query block fits the four LDS slices, every workgroup loads it once
+// and no slice is re-staged per tile (the host picks it; LAG builds keep the staged program).
+template <int MODE, bool STEPS3, int NQB = 16, bool RES = false>
 __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict__ shadow8, const uint4* __restrict__ qfrag8, int64_t n, int nsteps,
                                                          int64_t ntiles_run, int64_t tile_stride, const float* __restrict__ thr,
                                                          u64* __restrict__ bucket_key, u64* __restrict__ hits, unsigned* __restrict__ hit_cnt,
@@ -124,7 +126,10 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                                                          const float* __restrict__ qscale) {
     static_assert(MODE == MODE_FILTER || MODE == MODE_SAMPLE, "filter and sample passes only");
     static_assert(NQB == 16 || NQB == 8, "256 or 128 queries");
-    constexpr int kDmaPerIv = NQB / 4, kOpsPerIv = 1 + kDmaPerIv + kAPerIv;  // vector-memory operations per interval (see above)
+    constexpr int kDmaPerSlice = NQB / 4;                 // this wave's 1 KiB chunks of a slice
+    constexpr int kDmaPerIv = RES ? 0 : kDmaPerSlice;     // slice DMA per interval
+    constexpr int kOpsPerIv = 1 + kDmaPerIv + kAPerIv;    // vector-memory operations per interval (see above)
+    static_assert(!(RES && CODD_I8_LAG), "the resident program has no lagging half");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* lds_w = reinterpret_cast<unsigned*>(smem + 4 * kI8SliceBytes);
     float* lds_rs = reinterpret_cast<float*>(lds_w + kI8Words);                  // row scales of the tiles in flight
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         const int soff = q_s * kI8SliceBytes + wave * 1024;
         const unsigned dst = lds0 + (unsigned)(slot * kI8SliceBytes + wave * 1024);
 #pragma unroll
-        for (int j = 0; j < kDmaPerIv; ++j) i8_dma_b128(dst + j * 8192, lane16, rsrc_q, soff + j * 8192);
+        for (int j = 0; j < kDmaPerSlice; ++j) i8_dma_b128(dst + j * 8192, lane16, rsrc_q, soff + j * 8192);
         q_s = q_s + 1 == nsteps ? 0 : q_s + 1;
     };
 
@@ -390,8 +395,12 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     auto run = [&](auto LAG_) __attribute__((always_inline)) {
         constexpr int LAG = decltype(LAG_)::value;
         rs_dma(first_u, 0);  // (the first tile's scales)
-        stage_dma(0);
-        stage_dma(1);
+        if constexpr (RES) {
+            for (int s = 0; s < nsteps; ++s) stage_dma(s);  // the whole query block, once (nsteps <= 4)
+        } else {
+            stage_dma(0);
+            stage_dma(1);
+        }
         // corpus prologue: a lagging wave starts with step "-1" on an all-zero ring slot
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) ring[2][kk] = u32x4{0u, 0u, 0u, 0u};
@@ -420,13 +429,13 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                 pending = false;
             }
             __builtin_amdgcn_sched_barrier(0);
-            const unsigned qaddr = lds0 + (unsigned)(((t - LAG) & 3) * kI8SliceBytes + lane16);
+            const unsigned qaddr = lds0 + (unsigned)((RES ? c_s : ((t - LAG) & 3)) * kI8SliceBytes + lane16);
             i32x4 b[kBD];
             if (CODD_I8_EARLY_FRAGS) frag_prefetch(b, qaddr);
             __builtin_amdgcn_sched_barrier(0);
             rs_dma(w_u, w_ord);
 #ifndef CODD_I8_EXP_NODMA
-            stage_dma((t + 2) & 3);
+            if constexpr (!RES) stage_dma((t + 2) & 3);
 #endif
             load_a(ring[li]);
             i8_wait_vm<2 * kOpsPerIv>(ring[ci][0], ring[ci][1], ring[ci][2], ring[ci][3]);

@@ -34,14 +34,14 @@ def main():
     ix.set_option("filter", 1)
     out = {}
     for v in (0, 1):
-        ix.set_option("i8v2", v)
+        ix.set_option("i8v2", 2 * v)
         dist, idx = ix.search_tensors(q, k)
         torch.cuda.synchronize()
         out[f"ok{v}"] = bool(torch.equal(idx, i_ref) and torch.equal(dist, d_ref))
     res = {0: [], 1: []}
     for rnd in range(5):
         for v in (0, 1):
-            ix.set_option("i8v2", v)
+            ix.set_option("i8v2", 2 * v)  # 0: first-generation kernels; 2: the tile kernel wherever it applies
             ix.set_option("profile", 64)
             t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
             t0.record()

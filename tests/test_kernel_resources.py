@@ -29,7 +29,7 @@ def test_hot_kernels_do_not_spill():
     # the second-generation int8 kernel (filter_i8.h): two waves per SIMD and no scratch (a reload inside the loop would wait
     # vmcnt(0) and drain the hand-counted prefetch)
     tile = [name for name in rows if "i8_tile_kernel" in name]
-    assert len(tile) == 6, report  # filter (3-step-multiple rows / others) and sample, for 16 and for 8 query blocks
+    assert len(tile) == 12, report  # filter (3-step-multiple rows / others) and sample, for 16 and for 8 query blocks, staged and resident slices
     for name in tile:
         assert rows[name]["occ"] >= 2 and rows[name]["scratch"] == 0, f"{name}:\n{report}"
     full = next(name for name in rows if "gemm_filter_kernel<0, 8, 0, 0>" in name)
