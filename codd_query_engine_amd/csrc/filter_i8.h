@@ -1,4 +1,4 @@
-// filter_i8.h — the int8 filter GEMM for full query blocks (more than 128 queries, rows of more than 256 elements),
+// filter_i8.h — the int8 filter GEMM for batches of 65..256 queries on rows of 384 elements or more (3 K-steps),
 // second generation.  Same operands, same layouts, same hit lists as gemm_filter_kernel<MODE, 8, EL = 1> in
 // filter_gemm.h (which stays the kernel of every other shape); what changed is the schedule:
 //
@@ -26,7 +26,9 @@
 //     one (score, row) key per query and wave;
 //   * row scales reach the epilogue through LDS (one small DMA per wave and interval), not through global loads inside a
 //     conditional region;
-//   * the workgroup's hit-list bookkeeping rides on the interval barrier: no extra barriers per tile.
+//   * the workgroup's hit-list bookkeeping rides on the interval barrier: no extra barriers per tile;
+//   * instantiations: NQB = 16 / 8 query blocks (129..256 / 65..128 queries); RES: rows of <= 4 K-steps keep the whole query
+//     block in the four LDS slices (staged once per workgroup, no slice DMA per interval).
 //
 // LDS: 4 query slices x 32 KiB | 1088 bookkeeping words | 2 row-scale buffers x (256 + 16) floats | hit list.
 #pragma once
