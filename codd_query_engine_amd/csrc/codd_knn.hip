@@ -1426,7 +1426,7 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
 #define CODD_LAUNCH_TILE8_SAMPLE(NQB, RES)                                                                                                    \
     hipLaunchKernelGGL((i8_tile_kernel<MODE_SAMPLE, false, NQB, RES>), g, b, i8_lds_bytes(MODE_SAMPLE), st, shadow, qfrag, n, nsteps, ts, stride, \
                        nullptr, ix->bucket_max, nullptr, nullptr, 0, nullptr, ix->rscale, ix->qmeta)
-            const bool res = nsteps <= 4 && ix->resident_q;  // the query block fits the four LDS slices: loaded once per workgroup
+            const bool res = i8_tile_resident(nsteps, nbq) && ix->resident_q;  // the query block fits the four LDS slices: loaded once per workgroup
             if (nbq == 8) {
                 if (res) CODD_LAUNCH_TILE8_SAMPLE(16, true);
                 else CODD_LAUNCH_TILE8_SAMPLE(16, false);
@@ -1505,7 +1505,7 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
 #define CODD_LAUNCH_TILE8(S3, NQB, RES)                                                                                                              \
     hipLaunchKernelGGL((i8_tile_kernel<MODE_FILTER, S3, NQB, RES>), g, b, i8_lds_bytes(MODE_FILTER), st, shadow, qfrag, n, nsteps, ntiles, (int64_t)1, \
                        ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, ix->rscale, ix->qmeta)
-            const bool res = nsteps <= 4 && ix->resident_q;
+            const bool res = i8_tile_resident(nsteps, nbq) && ix->resident_q;
             if (nbq == 8) {
                 if (res) { if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(true, 16, true); else CODD_LAUNCH_TILE8(false, 16, true); }
                 else { if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(true, 16, false); else CODD_LAUNCH_TILE8(false, 16, false); }

@@ -111,6 +111,9 @@ constexpr int kAPerIv = 4;
 // SAMPLE: [0..511] = 256 u64 keys.
 constexpr int kI8Words = 1088;
 
+// does the resident program apply? (nbq: 32-query blocks of the batch: 8 -> NQB = 16, 4 -> NQB = 8)
+__host__ __device__ constexpr bool i8_tile_resident(int nsteps, int nbq) { return nsteps <= (nbq == 8 ? 4 : 8); }
+
 __host__ __device__ constexpr size_t i8_lds_bytes(int mode) {
     return (size_t)4 * kI8SliceBytes + kI8Words * 4 + kI8RsBufs * kI8RsStride * 4 + (mode == MODE_FILTER ? (size_t)kHitCap * 12 : 0);
 }
@@ -118,8 +121,9 @@ __host__ __device__ constexpr size_t i8_lds_bytes(int mode) {
 // STEPS3: the row has a multiple of 3 K-steps (the host picks the instantiation): tiles start at corpus-ring phase 0.
 // NQB: query blocks of 16 the launch multiplies: 16 (129..256 queries) or 8 (65..128: half the MFMAs, half the slice bytes;
 // the slices keep their 32 KiB slots and the bookkeeping its 256-query layout).
-// RES: rows of <= 4 K-steps (512 elements): the whole query block fits the four LDS slices, every workgroup loads it once
-// and no slice is re-staged per tile (the host picks it; LAG builds keep the staged program).
+// RES: the whole query block fits the four LDS slices (rows of <= 4 K-steps; <= 8 K-steps with 8 query blocks, whose slices
+// are half as big): every workgroup loads it once and no slice is re-staged per tile (the host picks it: i8_tile_resident();
+// LAG builds keep the staged program).
 template <int MODE, bool STEPS3, int NQB = 16, bool RES = false>
 __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict__ shadow8, const uint4* __restrict__ qfrag8, int64_t n, int nsteps,
                                                          int64_t ntiles_run, int64_t tile_stride, const float* __restrict__ thr,
@@ -132,6 +136,8 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     constexpr int kDmaPerIv = RES ? 0 : kDmaPerSlice;     // slice DMA per interval
     constexpr int kOpsPerIv = 1 + kDmaPerIv + kAPerIv;    // vector-memory operations per interval (see above)
     static_assert(!(RES && CODD_I8_LAG), "the resident program has no lagging half");
+    // LDS slot of a slice: 32 KiB; the resident program of 8 query blocks packs its 16 KiB slices (up to 8 K-steps fit)
+    constexpr int kSlotBytes = RES && NQB == 8 ? kI8SliceBytes / 2 : kI8SliceBytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* lds_w = reinterpret_cast<unsigned*>(smem + 4 * kI8SliceBytes);
     float* lds_rs = reinterpret_cast<float*>(lds_w + kI8Words);                  // row scales of the tiles in flight
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     int q_s = 0;
     auto stage_dma = [&](int slot) __attribute__((always_inline)) {
         const int soff = q_s * kI8SliceBytes + wave * 1024;
-        const unsigned dst = lds0 + (unsigned)(slot * kI8SliceBytes + wave * 1024);
+        const unsigned dst = lds0 + (unsigned)(slot * kSlotBytes + wave * 1024);
 #pragma unroll
         for (int j = 0; j < kDmaPerSlice; ++j) i8_dma_b128(dst + j * 8192, lane16, rsrc_q, soff + j * 8192);
         q_s = q_s + 1 == nsteps ? 0 : q_s + 1;
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         constexpr int LAG = decltype(LAG_)::value;
         rs_dma(first_u, 0);  // (the first tile's scales)
         if constexpr (RES) {
-            for (int s = 0; s < nsteps; ++s) stage_dma(s);  // the whole query block, once (nsteps <= 4)
+            for (int s = 0; s < nsteps; ++s) stage_dma(s);  // the whole query block, once
         } else {
             stage_dma(0);
             stage_dma(1);
@@ -431,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                 pending = false;
             }
             __builtin_amdgcn_sched_barrier(0);
-            const unsigned qaddr = lds0 + (unsigned)((RES ? c_s : ((t - LAG) & 3)) * kI8SliceBytes + lane16);
+            const unsigned qaddr = lds0 + (unsigned)((RES ? c_s : ((t - LAG) & 3)) * kSlotBytes + lane16);
             i32x4 b[kBD];
             if (CODD_I8_EARLY_FRAGS) frag_prefetch(b, qaddr);
             __builtin_amdgcn_sched_barrier(0);
