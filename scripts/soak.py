@@ -22,7 +22,9 @@ while time.time() < t_end:
     B = int(rng.choice([1, 2, 7, 8, 9, 31, 32, 33, 64, 100, 128, 129, 255, 256, 257, 300]))
     k = int(rng.choice([1, 5, 10, 10, 10, 33, 64, 65, 100]))
     if tile_only:
-        d = int(rng.choice([384, 512, 640, 768, 768, 1000, 1024]))
+        d = int(rng.choice([384, 512, 640, 768, 768, 896, 1000, 1024, 1152, 1536, 2048]))
+        if d > 1024:
+            dtype = str(rng.choice(["bf16", "f16"]))  # (f32 rows go up to 1024 elements)
         B = int(rng.integers(65, 257))
         n = int(rng.integers(6_000, 400_000))
     kind = str(rng.choice(["random", "clustered", "dupes"]))
