@@ -28,7 +28,8 @@
 //     conditional region;
 //   * the workgroup's hit-list bookkeeping rides on the interval barrier: no extra barriers per tile;
 //   * instantiations: NQB = 16 / 8 query blocks (129..256 / 65..128 queries); RES: rows of <= 4 K-steps keep the whole query
-//     block in the four LDS slices (staged once per workgroup, no slice DMA per interval).
+//     block in the four LDS slices (staged once per workgroup, no slice DMA per interval) and synchronise once per tile
+//     instead of once per K-step (hit lists and sample keys double-buffered by tile parity).
 //
 // LDS: 4 query slices x 32 KiB | 1088 bookkeeping words | 2 row-scale buffers x (256 + 16) floats | hit list.
 #pragma once
@@ -136,6 +137,11 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     constexpr int kDmaPerIv = RES ? 0 : kDmaPerSlice;     // slice DMA per interval
     constexpr int kOpsPerIv = 1 + kDmaPerIv + kAPerIv;    // vector-memory operations per interval (see above)
     static_assert(!(RES && CODD_I8_LAG), "the resident program has no lagging half");
+    // The resident program synchronises ONCE per tile (nothing is staged cooperatively): the workgroup's shared state is
+    // then double-buffered by tile parity — two half hit lists with their counters, two sets of sample keys — so that
+    // what the barrier inside tile k hands over (tile k - 1's) is not written again before the barrier inside tile k + 1.
+    constexpr int kLists = RES ? 2 : 1;
+    constexpr unsigned kListCap = (unsigned)kHitCap / kLists;
     // LDS slot of a slice: 32 KiB; the resident program of 8 query blocks packs its 16 KiB slices (up to 8 K-steps fit)
     constexpr int kSlotBytes = RES && NQB == 8 ? kI8SliceBytes / 2 : kI8SliceBytes;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -168,9 +174,12 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             lds_w[576 + tid] = __float_as_uint(th);
             lds_w[320 + tid] = __float_as_uint(qscale[tid]);
         }
-        if (tid == 0) lds_w[256] = 0u;
+        if (tid < kLists) lds_w[256 + tid] = 0u;
     } else {
-        if (tid < 256) lds_k[tid] = 0ull;
+        if (tid < 256) {
+            lds_k[tid] = 0ull;
+            if (kLists == 2) lds_k[256 + tid] = 0ull;
+        }
     }
 
     const int lane16 = lane * 16;
@@ -240,6 +249,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         int c = lane & 15, lg = lane >> 4;
         asm volatile("" : "+v"(c), "+v"(lg));
         const int64_t tile = cu * tile_stride;
+        const unsigned par = kLists == 2 ? (unsigned)(ord & 1) : 0u;  // which half of the double-buffered shared state this tile writes
         const float* rsb = lds_rs + (ord & 1) * kI8RsStride;
         const unsigned row0 = (unsigned)(tile * kTileRows) + (unsigned)(wave * 32 + 4 * lg);  // + 16 * rs + r
         const f32x4 rsc0 = *reinterpret_cast<const f32x4*>(rsb + wave * 32 + 4 * lg);
@@ -274,12 +284,13 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                     // every exec-mask test waits for the compare), so the common case — no lane holds more than one hit among
                     // its 8 rows — runs straight-line: the per-value tests select the lane's hit and count them, one append.
                     auto append = [&](float val, int i) __attribute__((always_inline)) {
-                        const unsigned slot = atomicAdd(&lds_w[256], 1u);
+                        const unsigned slot = atomicAdd(&lds_w[256 + par], 1u);
                         const unsigned row = row0 + (unsigned)(16 * (i >> 2) + (i & 3));
-                        if (slot < (unsigned)kHitCap) {
-                            lds_hits[slot * 3 + 0] = __float_as_uint(val);   // (the query's scale is applied by the flush)
-                            lds_hits[slot * 3 + 1] = row;
-                            lds_hits[slot * 3 + 2] = q;
+                        if (slot < kListCap) {
+                            unsigned* e = lds_hits + (par * kListCap + slot) * 3;
+                            e[0] = __float_as_uint(val);   // (the query's scale is applied by the flush)
+                            e[1] = row;
+                            e[2] = q;
                         }
 #ifndef CODD_I8_EXP_NOGLOBAL  // (diagnostic: hits past a full list are dropped)
                         else {
@@ -343,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                     m = max((int)s32[0], (int)s32[1]);
                     if (lg == 0 && m != INT_MIN) {
                         const u64 key = make_key((float)(m >> 5) * rsl, wrow0 + (unsigned)(31 - (m & 31)));
-                        atomicMax(reinterpret_cast<unsigned long long*>(&lds_k[qb * 16 + c]), (unsigned long long)key);
+                        atomicMax(reinterpret_cast<unsigned long long*>(&lds_k[par * 256 + qb * 16 + c]), (unsigned long long)key);
                     }
                 }
             };
@@ -458,26 +469,31 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
 #ifdef CODD_I8_EXP_NOBARRIER
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kAPerIv + kOpsPerIv) : "memory");  // diagnostic (racy)
 #else
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kAPerIv + kOpsPerIv) : "memory");
+            // (the resident program: one barrier per tile, in its second interval — slices are read-only, corpus fragments
+            // and row scales belong to the wave, the hit lists / sample keys are double-buffered by tile parity)
+            if (RES && w_s != 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kAPerIv + kOpsPerIv) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kAPerIv + kOpsPerIv) : "memory");
 #endif
-            // every wave has folded tile w_ord - 1 by the end of the interval with w_s == 1, and no epilogue runs in the
-            // next interval (nsteps >= 3): the shared counters are stable until the next barrier
+            // every wave has folded tile w_ord - 1 when the barrier of the interval with w_s == 1 releases, and no wave
+            // writes that tile's half of the shared state again before the barrier inside the next tile (staged program:
+            // no epilogue runs in the next interval, nsteps >= 3): the counters read here are stable
             if (w_s == 1 && w_ord >= 1) {
+                const unsigned par = kLists == 2 ? (unsigned)((w_ord - 1) & 1) : 0u;
                 if (MODE == MODE_FILTER) {
-                    const unsigned cnt = lds_w[256];
-                    if (cnt > (unsigned)(CODD_FLUSH_AT)) {
+                    const unsigned cnt = lds_w[256 + par];
+                    if (cnt > (kLists == 2 ? kListCap / 2 : (unsigned)(CODD_FLUSH_AT))) {
                         // (per-query ranges reserved with one global atomic each: on clustered corpora a tile fills the list
                         // and every workgroup flushes every tile; one atomic per hit serialises on 256 counters)
-                        flush_hits_binned(lds_hits, cnt < (unsigned)kHitCap ? cnt : (unsigned)kHitCap, tid, lds_w + 832, hits, hit_cnt, cap_q, reinterpret_cast<const float*>(lds_w + 320));
+                        flush_hits_binned(lds_hits + par * kListCap * 3, cnt < kListCap ? cnt : kListCap, tid, lds_w + 832, hits, hit_cnt, cap_q, reinterpret_cast<const float*>(lds_w + 320));
                         __syncthreads();
-                        if (tid == 0) lds_w[256] = 0u;
+                        if (tid == 0) lds_w[256 + par] = 0u;
                     }
                 } else if (pub_ord == w_ord - 1 && pub_ord < my_tiles) {
                     if (tid < 256) {
-                        u64 key = lds_k[tid];
+                        u64 key = lds_k[par * 256 + tid];
                         if (key) key = make_key(key_score(key) * qscale[tid], key_row(key));  // the fold ran on acc * rscale
                         bucket_key[(int64_t)tid * ntiles_run + (first_u + (int64_t)pub_ord * G)] = key;
-                        lds_k[tid] = 0ull;
+                        lds_k[par * 256 + tid] = 0ull;
                     }
                     ++pub_ord;
                 }
@@ -520,7 +536,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         if (pending) epilogue(p_u, p_ord);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (MODE == MODE_SAMPLE && pub_ord < my_tiles && tid < 256) {
-            u64 key = lds_k[tid];
+            u64 key = lds_k[(kLists == 2 ? (pub_ord & 1) * 256 : 0) + tid];
             if (key) key = make_key(key_score(key) * qscale[tid], key_row(key));
             bucket_key[(int64_t)tid * ntiles_run + (first_u + (int64_t)pub_ord * G)] = key;
         }
@@ -529,12 +545,16 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     else run(std::integral_constant<int, 0>{});
 
     if (MODE == MODE_FILTER) {
-        const unsigned cnt = lds_w[256];
-        if (cnt > (unsigned)kHitCap && tid == 0) atomicOr(&flags[FLAG_WG_OVERFLOW], 1u);  // statistics only
-        __syncthreads();  // everyone has read cnt (lds_w[0..255] is about to be reused as the flush's scratch)
+#pragma unroll
+        for (int p = 0; p < kLists; ++p) {
+            const unsigned cnt = lds_w[256 + p];
+            if (cnt > kListCap && tid == 0) atomicOr(&flags[FLAG_WG_OVERFLOW], 1u);  // statistics only
+            __syncthreads();  // everyone has read cnt (lds_w[0..255] is about to be reused as the flush's scratch)
 #ifndef CODD_I8_EXP_NOFLUSH  // (diagnostic: the hits of the last tiles are dropped)
-        flush_hits_binned(lds_hits, cnt < (unsigned)kHitCap ? cnt : (unsigned)kHitCap, tid, lds_w, hits, hit_cnt, cap_q, reinterpret_cast<const float*>(lds_w + 320));
+            flush_hits_binned(lds_hits + p * kListCap * 3, cnt < kListCap ? cnt : kListCap, tid, lds_w, hits, hit_cnt, cap_q, reinterpret_cast<const float*>(lds_w + 320));
 #endif
+            if (p + 1 < kLists) __syncthreads();  // (the scratch is reused by the other half's flush)
+        }
     }
 }
 
