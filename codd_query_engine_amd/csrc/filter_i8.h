@@ -107,7 +107,8 @@ __device__ __forceinline__ void lgkm_wait_asm(i32x4& v) {
 // vector-memory operations per interval, in issue order: scale DMA, kDmaPerIv slice DMA, kAPerIv corpus loads
 // (kDmaPerIv = NQB / 4: a slice of 16 NQB queries is NQB / 2 chunks of 1 KiB per wave pair... 2 NQB KiB in all, 8 waves)
 constexpr int kAPerIv = 4;
-// bookkeeping words behind the slices: [0..255] pre-test thresholds, transposed ([query & 15][query >> 4]); [256] hit count;
+// bookkeeping words behind the slices: [0..255] pre-test thresholds of query q = 16 qb + c at [((qb >> 2) * 16 + c) * 4 + (qb & 3)]
+// (a lane's 16 thresholds are four 16-byte reads, consecutive lanes read consecutive 16 bytes: no bank conflict); [256], [257] hit counts;
 // [320..575] query scales; [576..831] exact thresholds (thr / qscale), by query; [832..1087] scratch of the in-loop flush.
 // SAMPLE: [0..511] = 256 u64 keys.
 constexpr int kI8Words = 1088;
@@ -167,9 +168,9 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             // the pre-test (largest accumulator of a block pair x the block's scale) is only conclusive for a positive
             // threshold: thresholds <= 0 (and NaN: a zero query) always take the exact per-value test
 #ifdef CODD_I8_EXP_NOHITS
-            lds_w[(tid & 15) * 16 + (tid >> 4)] = __float_as_uint(INFINITY);  // diagnostic: no pair ever passes the pre-test
+            lds_w[(((tid >> 4) >> 2) * 16 + (tid & 15)) * 4 + ((tid >> 4) & 3)] = __float_as_uint(INFINITY);  // diagnostic: no pair ever passes the pre-test
 #else
-            lds_w[(tid & 15) * 16 + (tid >> 4)] = __float_as_uint(th > 0.0f ? th : -INFINITY);
+            lds_w[(((tid >> 4) >> 2) * 16 + (tid & 15)) * 4 + ((tid >> 4) & 3)] = __float_as_uint(th > 0.0f ? th : -INFINITY);
 #endif
             lds_w[576 + tid] = __float_as_uint(th);
             lds_w[320 + tid] = __float_as_uint(qscale[tid]);
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             // pair's largest accumulator is therefore EXACT at pair level: it passes iff some value of the pair passes.
             f32x4 thp4[NQB / 4];
 #pragma unroll
-            for (int j = 0; j < NQB / 4; ++j) thp4[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(lds_w) + c * 16 + 4 * j);
+            for (int j = 0; j < NQB / 4; ++j) thp4[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(lds_w) + (j * 16 + c) * 4);
             const float rsl = fmaxf(fmaxf(fmaxf(rsc0[0], rsc0[1]), fmaxf(rsc0[2], rsc0[3])), fmaxf(fmaxf(rsc1[0], rsc1[1]), fmaxf(rsc1[2], rsc1[3])));
 #pragma unroll
             for (int qb = 0; qb < NQB; ++qb) {
