@@ -766,10 +766,17 @@ struct codd_knn_index : WorkBufs {
     hipStream_t shadow_stream = nullptr;
     hipEvent_t shadow_ready = nullptr;
     int64_t stat_shadow_builds = 0;
+    int64_t shadow_nomem_epoch = -1;   // row epoch at which allocating the bf16 shadow failed: not retried until rows change
+    int64_t stat_shadow_nomem = 0;
+    int debug_fail_shadow_alloc = 0;   // test hook ("debug_fail_shadow_alloc"): the next bf16-shadow allocation reports out of memory
     // stored rows written on a caller's stream (upsert_device): searches on other streams wait for this on the device
     hipEvent_t rows_ready = nullptr;
     hipStream_t rows_stream = nullptr;
     bool rows_event_set = false;
+    // ... and rows read on a caller's stream outside a search (copy_rows_f32): the next writer on another stream waits for it
+    hipEvent_t reader_done = nullptr;
+    hipStream_t reader_stream = nullptr;
+    bool reader_event_set = false;
     // staging of codd_knn_upsert_host (kept between calls: the indexer job upserts in small batches)
     float* stage_vec = nullptr;   int64_t stage_vec_cap = 0;
     int64_t* stage_slot = nullptr; int64_t stage_slot_cap = 0;
@@ -1262,6 +1269,19 @@ int wait_rows(codd_knn_index* ix, hipStream_t st) {
     return CODD_KNN_OK;
 }
 
+// Before a derived buffer is freed (a shadow outgrown by the corpus): wait on the host for the streams that search THIS index
+// — what they have enqueued so far may still read the old allocation — not for the whole device.  (Growth is the one
+// place where a search call blocks; steady-state searches never do.)
+int wait_searching_streams(codd_knn_index* ix) {
+    for (WorkSlot& w : ix->slots) {
+        if (!w.used) continue;
+        if (!w.handover) HIP_TRY(hipEventCreateWithFlags(&w.handover, hipEventDisableTiming));
+        if (hipEventRecord(w.handover, w.stream) == hipSuccess) HIP_TRY(hipEventSynchronize(w.handover));
+        else (void)hipGetLastError();  // (a stream that no longer exists has nothing in flight)
+    }
+    return CODD_KNN_OK;
+}
+
 // The bf16 shadow, like the int8 one, is derived data: (re)built from the stored rows on the searching stream whenever rows
 // have been written since the last build, over the dirty row range only.  An index that only ever sees batches of <= 256
 // queries (the int8 filter) never allocates it: 38 GB instead of 54 GB for the 10M x 768 fp32 corpus.
@@ -1274,12 +1294,23 @@ int ensure_shadow(codd_knn_index* ix, hipStream_t st) {
     const int64_t need = (n + kTileRows - 1) / kTileRows * kTileRows;
     int64_t first = ix->dirty16_lo, m = ix->dirty16_hi - ix->dirty16_lo;
     if (need > ix->shadow_rows) {
-        HIP_TRY(hipDeviceSynchronize());  // every stream that may still read the old allocation is done with it
+        // A failed allocation is remembered until rows change (no multi-GB hipMalloc retried by every search); the caller
+        // answers the search another way (search_impl: the int8 filter or the exact scan).
+        if (ix->shadow_nomem_epoch == ix->epoch) return CODD_KNN_ENOMEM;
+        int rc;
+        if ((rc = wait_searching_streams(ix)) != 0) return rc;
         if (ix->shadow) (void)hipFree(ix->shadow);
         ix->shadow = nullptr; ix->shadow_rows = 0;
         const int64_t rows = need + need / 8;
         const int64_t rows_al = (rows + kTileRows - 1) / kTileRows * kTileRows;
-        HIP_TRY(hipMalloc((void**)&ix->shadow, (size_t)rows_al * ix->dpad * 2));
+        hipError_t me = ix->debug_fail_shadow_alloc ? hipErrorOutOfMemory : hipMalloc((void**)&ix->shadow, (size_t)rows_al * ix->dpad * 2);
+        if (me != hipSuccess) {
+            (void)hipGetLastError();
+            ix->shadow = nullptr;
+            ix->shadow_nomem_epoch = ix->epoch;
+            ix->stat_shadow_nomem++;
+            return fail(CODD_KNN_ENOMEM, "bf16 shadow: %s", hipGetErrorString(me));
+        }
         ix->shadow_rows = rows_al;
         HIP_TRY(hipMemsetAsync(ix->shadow, 0, (size_t)rows_al * ix->dpad * 2, st));  // rows beyond the count are masked, their bytes only have to be defined
         first = 0; m = n;
@@ -1320,7 +1351,8 @@ int ensure_shadow8(codd_knn_index* ix, hipStream_t st) {
     }
     if (need > ix->shadow8_rows) {
         // (every stream that may still read the old allocation has to be done with it)
-        HIP_TRY(hipDeviceSynchronize());
+        int rcw;
+        if ((rcw = wait_searching_streams(ix)) != 0) return rcw;
         if (ix->shadow8) (void)hipFree(ix->shadow8);
         if (ix->rscale) (void)hipFree(ix->rscale);
         ix->shadow8 = nullptr; ix->rscale = nullptr; ix->shadow8_rows = 0;
@@ -1615,8 +1647,7 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
     if ((rc = ensure_buf(&ix->qn, &ix->qn_cap, (int64_t)B * ix->dpad)) != 0) return rc;
     if ((rc = ensure_buf(&ix->keys_tmp, &ix->keys_tmp_cap, (int64_t)B * k)) != 0) return rc;
     if ((rc = wait_rows(ix, st)) != 0) return rc;
-    const bool use_filter = n > 0 && filter_applies(ix, B, k);
-    const bool fused_prep = use_filter && B <= kTileQ;
+    bool use_filter = n > 0 && filter_applies(ix, B, k);
     if (ix->eps_r_copied) {
         if (hipEventQuery(ix->eps_r_copied) == hipSuccess) ix->eps_r_known = *ix->eps_r_host;
         else (void)hipGetLastError();  // "not ready" must not surface in a later error check
@@ -1652,8 +1683,22 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
     const bool cooling = ix->cooldown_left > 0;
     if (cooling && use_filter) ix->cooldown_left--;
     // the int8 filter: every pass of <= 256 queries prepares its own block (a batch above 256 queries is several passes)
-    const bool use8 = use_filter && !cooling && ix->shadow8_enabled && (B <= ix->shadow8_max_batch || (B > kTileQ && ix->shadow8_max_batch >= kTileQ)) &&
-                      CODD_MFMA16 && ix->eps_r_known <= ix->shadow8_max_eps;
+    const bool can8 = use_filter && ix->shadow8_enabled && (B <= ix->shadow8_max_batch || (B > kTileQ && ix->shadow8_max_batch >= kTileQ)) && CODD_MFMA16;
+    bool use8 = can8 && !cooling && ix->eps_r_known <= ix->shadow8_max_eps;
+    if (use_filter && !use8) {
+        // the bf16 filter: its shadow is allocated by the first search that needs it.  When HBM cannot hold it the search is
+        // still answered exactly — through the int8 filter where the index may use it (a cooldown or a wide eps_r only make
+        // that one slower), else by the exact scan — and the failed allocation is not retried until rows change.
+        if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
+        rc = ensure_shadow(ix, st);
+        if (rc == CODD_KNN_ENOMEM) {
+            if (can8) use8 = true;
+            else use_filter = false;
+        } else if (rc != 0) {
+            return rc;
+        }
+    }
+    const bool fused_prep = use_filter && B <= kTileQ;
     const int dpad8 = dpad8_of(ix);
     auto prep8 = [&](int q0, int nq) -> int {
         hipLaunchKernelGGL(prep_queries8_kernel, dim3(kTileQ / 4), dim3(256), 0, st, dev_queries + (int64_t)q0 * ix->dim, nq, ix->dim, ix->dpad, dpad8,
@@ -1668,8 +1713,6 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
         if ((rc = ensure_buf(&ix->qfrag8, &ix->qfrag8_cap, (int64_t)kTileQ * (dpad8 / 16))) != 0) return rc;
         if (!ix->qmeta) HIP_TRY(hipMalloc((void**)&ix->qmeta, 512 * sizeof(float)));
     } else if (fused_prep) {
-        if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
-        if ((rc = ensure_shadow(ix, st)) != 0) return rc;
         hipLaunchKernelGGL(prep_queries_kernel, dim3(kTileQ / 4), dim3(256), 0, st, dev_queries, B, ix->dim, ix->dpad, ix->qn,
                            reinterpret_cast<uint2*>(ix->qfrag), reinterpret_cast<unsigned*>(ix->ctl), (int)(sizeof(FilterCtl) / 4));
         HIP_TRY(hipGetLastError());
@@ -1689,7 +1732,6 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
     if (!use_filter)  // small batches: the per-block partials merge straight into the caller's buffers
         return exact_scan(ix, ix->qn, B, k, row_base, out_keys, out_dist, out_rows, st);
     if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
-    if (!use8 && (rc = ensure_shadow(ix, st)) != 0) return rc;
     for (int q0 = 0; q0 < B; q0 += kTileQ) {
         const int nq = B - q0 < kTileQ ? B - q0 : kTileQ;
         if (use8 && (rc = prep8(q0, nq)) != 0) return rc;
@@ -1767,6 +1809,7 @@ int codd_knn_destroy(codd_knn_index* ix) {
     if (ix->shadow8_ready) (void)hipEventDestroy(ix->shadow8_ready);
     if (ix->shadow_ready) (void)hipEventDestroy(ix->shadow_ready);
     if (ix->rows_ready) (void)hipEventDestroy(ix->rows_ready);
+    if (ix->reader_done) (void)hipEventDestroy(ix->reader_done);
     if (ix->stage_vec) (void)hipFree(ix->stage_vec);
     if (ix->stage_slot) (void)hipFree(ix->stage_slot);
     if (ix->watch_copied) (void)hipEventDestroy(ix->watch_copied);
@@ -1844,6 +1887,7 @@ int codd_knn_upsert_host(codd_knn_index* ix, const int64_t* host_slots, const fl
         if (rc == 0 && hipDeviceSynchronize() != hipSuccess) rc = fail(CODD_KNN_EDEVICE, "ingest kernel failed%s");
     }
     ix->rows_event_set = false;  // (everything is complete on the device)
+    ix->reader_event_set = false;
     if (rc == 0) {
         if (max_slot + 1 > ix->count) ix->count = max_slot + 1;
         rows_written(ix, min_slot, max_slot + 1);
@@ -1871,6 +1915,11 @@ int codd_knn_upsert_device(codd_knn_index* ix, int64_t first_slot, const float* 
         if (hipEventRecord(w.handover, w.stream) == hipSuccess) HIP_TRY(hipStreamWaitEvent(wst, w.handover, 0));
         else (void)hipGetLastError();  // (a stream that no longer exists has nothing in flight)
     }
+    // ... and for the previous writer, when that was another stream: rows_ready is ONE event, re-recorded by every write, so
+    // chaining the writers makes the last record cover every earlier write (a reader only ever waits for the last one)
+    if (ix->rows_event_set && ix->rows_stream != wst) HIP_TRY(hipStreamWaitEvent(wst, ix->rows_ready, 0));
+    // ... and for streams that only READ rows outside a search (codd_knn_copy_rows_f32)
+    if (ix->reader_event_set && ix->reader_stream != wst) HIP_TRY(hipStreamWaitEvent(wst, ix->reader_done, 0));
     int rc = launch_normalize(ix->dtype, dev_vecs, n, ix->dim, ix->dpad, normalize, nullptr, first_slot, ix->rows, nullptr, wst);
     if (rc != 0) return rc;
     // ... and searches on other streams wait for this write (wait_rows)
@@ -2013,18 +2062,28 @@ int codd_knn_approx_scores(codd_knn_index* ix, const float* dev_queries, int B, 
     return CODD_KNN_OK;
 }
 
-int codd_knn_copy_rows_f32(const codd_knn_index* ix, int64_t first, int64_t n, float* dev_out, void* stream) {
+int codd_knn_copy_rows_f32(codd_knn_index* ix, int64_t first, int64_t n, float* dev_out, void* stream) {
     if (!ix || first < 0 || n < 0 || first + n > ix->count || (n > 0 && !dev_out)) return fail(CODD_KNN_EINVAL, "bad copy_rows range%s");
     if (n == 0) return CODD_KNN_OK;
     DeviceGuard guard(ix->device);
     const dim3 grid((unsigned)((n + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(ix->mu);
+    // a read of the stored rows on the caller's stream: behind the last asynchronous write (as a search is), and the next
+    // writer on another stream is ordered behind it (reader_done)
+    int rc;
+    if ((rc = wait_rows(ix, st)) != 0) return rc;
     switch (ix->dtype) {
         case DT_F32: hipLaunchKernelGGL(widen_rows_kernel<DT_F32>, grid, block, 0, st, ix->rows, first, n, ix->dim, ix->dpad, dev_out); break;
         case DT_BF16: hipLaunchKernelGGL(widen_rows_kernel<DT_BF16>, grid, block, 0, st, ix->rows, first, n, ix->dim, ix->dpad, dev_out); break;
         default: hipLaunchKernelGGL(widen_rows_kernel<DT_F16>, grid, block, 0, st, ix->rows, first, n, ix->dim, ix->dpad, dev_out); break;
     }
     HIP_TRY(hipGetLastError());
+    if (!ix->reader_done) HIP_TRY(hipEventCreateWithFlags(&ix->reader_done, hipEventDisableTiming));
+    if (ix->reader_event_set && ix->reader_stream != st) HIP_TRY(hipStreamWaitEvent(st, ix->reader_done, 0));  // (one event: chain the readers too)
+    HIP_TRY(hipEventRecord(ix->reader_done, st));
+    ix->reader_stream = st;
+    ix->reader_event_set = true;
     return CODD_KNN_OK;
 }
 
@@ -2192,6 +2251,11 @@ int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {
         return CODD_KNN_OK;
     }
 #endif
+    if (strcmp(key, "debug_fail_shadow_alloc") == 0) {  // test hook: the bf16 shadow's allocation fails as if HBM were full
+        ix->debug_fail_shadow_alloc = value != 0;
+        if (!value) ix->shadow_nomem_epoch = -1;
+        return CODD_KNN_OK;
+    }
     if (strcmp(key, "all_normalized") == 0) {
         // 0: the caller knows of rows that are not unit vectors (a persisted index written with normalize = 0): both filters
         // off, every search takes the exact scan.  The flag cannot be switched back on from outside.
@@ -2288,6 +2352,7 @@ int codd_knn_get_stat(const codd_knn_index* ix, const char* key, int64_t* out) {
     else if (strcmp(key, "filter_passes") == 0) *out = ix->stat_filter_passes;
     else if (strcmp(key, "shadow8_builds") == 0) *out = ix->stat_shadow8_builds;
     else if (strcmp(key, "shadow16_builds") == 0) *out = ix->stat_shadow_builds;
+    else if (strcmp(key, "shadow16_alloc_failures") == 0) *out = ix->stat_shadow_nomem;
     else if (strcmp(key, "all_normalized") == 0) *out = ix->all_normalized ? 1 : 0;
     else if (strcmp(key, "shadow8_passes") == 0) *out = ix->stat_shadow8_passes;
     else if (strcmp(key, "i8v2_passes") == 0) *out = ix->stat_i8v2_passes;

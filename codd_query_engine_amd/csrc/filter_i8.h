@@ -49,6 +49,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kI8SliceBytes = 32768;  // one 128-wide K slice of the 256-query block
 constexpr int kI8RsBufs = 2;          // row-scale buffers (tile ordinal & 1): a tile's scales are read (its epilogue, at the start of the next tile) before the tile after next requests its own
 constexpr int kI8RsStride = 272;      // floats per buffer: 256 row scales + 8 per-wave maxima (+ pad)
+#if !CODD_EXPERIMENTS && (defined(CODD_I8_BDEPTH) || defined(CODD_I8_EARLY_FRAGS) || defined(CODD_I8_LAG))
+#error "CODD_I8_BDEPTH / CODD_I8_EARLY_FRAGS / CODD_I8_LAG are schedule experiments: only their defaults are under test; -DCODD_EXPERIMENTS=1 builds (build_variant) may set them"
+#endif
 #ifndef CODD_I8_BDEPTH
 #define CODD_I8_BDEPTH 4              // query-fragment register sets in flight
 #endif
@@ -57,7 +60,10 @@ constexpr int kBD = CODD_I8_BDEPTH;
 #define CODD_I8_EARLY_FRAGS 1         // the first fragment reads of a K-step go out before the interval's DMA / corpus-load instructions (0: behind them)
 #endif
 #ifndef CODD_I8_LAG
-#define CODD_I8_LAG 0                 // 1: waves 4..7 run one K-step behind waves 0..3 (measured slower: an epilogue takes longer than the partner's MFMAs of one step, profiles/r2/i8_tile_ablation.txt)
+#define CODD_I8_LAG 0                 // 1: waves 4..7 run one K-step behind waves 0..3 (measured 12 % slower twice, profiles/r2/i8_tile_ablation.txt; experiment builds only)
+#endif
+#ifndef CODD_I8_FUSE_EPI
+#define CODD_I8_FUSE_EPI 1            // the tile-structured filter program tests tile i's accumulators INSIDE the first K-step of tile i + 1 (see epi_pair)
 #endif
 
 // ---- hand-issued memory operations (see the header) --------------------------------------------------------------
@@ -79,13 +85,13 @@ __device__ __forceinline__ void i8_load_b128_nt(u32x4& dst, int voff, i32x4 rsrc
 __device__ __forceinline__ void i8_dma_b128(unsigned lds_addr, int voff, i32x4 rsrc, int soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rsrc),
                  "s"(__builtin_amdgcn_readfirstlane(soff))
-                 : "memory");
+                 : "memory", "m0");
 }
 // 64 lanes x 4 bytes: global (rsrc + voff + soff) -> LDS [lds_addr + 4 * lane]
 __device__ __forceinline__ void i8_dma_b32(unsigned lds_addr, int voff, i32x4 rsrc, int soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rsrc),
                  "s"(__builtin_amdgcn_readfirstlane(soff))
-                 : "memory");
+                 : "memory", "m0");
 }
 template <int N>
 __device__ __forceinline__ void i8_wait_vm(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
@@ -107,8 +113,7 @@ __device__ __forceinline__ void lgkm_wait_asm(i32x4& v) {
 // vector-memory operations per interval, in issue order: scale DMA, kDmaPerIv slice DMA, kAPerIv corpus loads
 // (kDmaPerIv = NQB / 4: a slice of 16 NQB queries is NQB / 2 chunks of 1 KiB per wave pair... 2 NQB KiB in all, 8 waves)
 constexpr int kAPerIv = 4;
-// bookkeeping words behind the slices: [0..255] pre-test thresholds of query q = 16 qb + c at [((qb >> 2) * 16 + c) * 4 + (qb & 3)]
-// (a lane's 16 thresholds are four 16-byte reads, consecutive lanes read consecutive 16 bytes: no bank conflict); [256], [257] hit counts;
+// bookkeeping words behind the slices: [0..127] pre-test thresholds, two bf16 per word (layout: the kernel's set-up); [256], [257] hit counts;
 // [320..575] query scales; [576..831] exact thresholds (thr / qscale), by query; [832..1087] scratch of the in-loop flush.
 // SAMPLE: [0..511] = 256 u64 keys.
 constexpr int kI8Words = 1088;
@@ -155,6 +160,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
 
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned n_rows = (unsigned)n;  // (row slots are 32-bit: keys carry them in their low word)
 
     const int64_t G = gridDim.x;
     const int64_t first_u = blockIdx.x;
@@ -166,12 +172,17 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         if (tid < 256) {
             const float th = thr[tid] / qscale[tid];  // the test runs on acc * rscale[row]
             // the pre-test (largest accumulator of a block pair x the block's scale) is only conclusive for a positive
-            // threshold: thresholds <= 0 (and NaN: a zero query) always take the exact per-value test
+            // threshold: thresholds <= 0 (and NaN: a zero query) always take the exact per-value test.  Stored rounded DOWN to
+            // bf16 (truncation of a positive float; -inf and +inf are exact), query q = 16 qb + c in half (qb & 1) of word
+            // [(((qb >> 1) >> 2) * 16 + c) * 4 + ((qb >> 1) & 3)]: a lane's 16 thresholds are two 16-byte reads, consecutive
+            // lanes read consecutive 16 bytes (no bank conflict)
 #ifdef CODD_I8_EXP_NOHITS
-            lds_w[(((tid >> 4) >> 2) * 16 + (tid & 15)) * 4 + ((tid >> 4) & 3)] = __float_as_uint(INFINITY);  // diagnostic: no pair ever passes the pre-test
+            const float pre = INFINITY;  // diagnostic: no pair ever passes the pre-test
 #else
-            lds_w[(((tid >> 4) >> 2) * 16 + (tid & 15)) * 4 + ((tid >> 4) & 3)] = __float_as_uint(th > 0.0f ? th : -INFINITY);
+            const float pre = th > 0.0f ? th : -INFINITY;
 #endif
+            const int qb = tid >> 4, c = tid & 15, j = qb >> 1;
+            reinterpret_cast<unsigned short*>(lds_w)[2 * (((j >> 2) * 16 + c) * 4 + (j & 3)) + (qb & 1)] = (unsigned short)(__float_as_uint(pre) >> 16);
             lds_w[576 + tid] = __float_as_uint(th);
             lds_w[320 + tid] = __float_as_uint(qscale[tid]);
         }
@@ -244,17 +255,100 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     };
 
     // ---- epilogues ----
-    auto epilogue = [&](int64_t cu, int ord) __attribute__((always_inline)) {
+    // FILTER: what a lane needs to test a tile's accumulators, set up once per tile (epi_begin); the test of one block pair
+    // — (2 row blocks of the wave) x (query block qb) — is epi_pair.  The standalone epilogue runs the 16 pairs back to back;
+    // the tile-structured program (CODD_I8_FUSE_EPI) runs pair qb right in front of the first MFMAs of the NEXT tile that
+    // overwrite its accumulators (first K-step, K half 0, query block qb): all eight waves used to reach the epilogue
+    // together and the matrix pipe idled for its whole length; fused, a wave that takes the rare per-value path (LDS atomic
+    // round trip inside a branch) leaves its SIMD partner's MFMAs running.
+    struct EpiCtx {
+        unsigned par;              // which half of the double-buffered shared state the tile writes (uniform)
+        unsigned wrow0;            // first row of the wave's 32-row block (uniform)
+        float rsl;                 // its scale (uniform; NaN: the whole block lies past the count — every comparison fails)
+        u32x4 thw[NQB / 8];        // the lane's NQB pre-test thresholds, two bf16 per word (see the kernel's set-up)
+    };
+    auto epi_begin = [&](int64_t cu, int ord, bool valid) __attribute__((always_inline)) {
         // lane coordinates re-derived behind an opaque asm: hipcc otherwise hoists every per-query-block address of this
         // body out of the interval loop and keeps dozens of registers of loop invariants alive across the MFMA phases
-        int c = lane & 15, lg = lane >> 4;
-        asm volatile("" : "+v"(c), "+v"(lg));
+        EpiCtx e;
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        const int c = l & 15;
         const int64_t tile = cu * tile_stride;
-        const unsigned par = kLists == 2 ? (unsigned)(ord & 1) : 0u;  // which half of the double-buffered shared state this tile writes
-        const float* rsb = lds_rs + (ord & 1) * kI8RsStride;
-        const unsigned row0 = (unsigned)(tile * kTileRows) + (unsigned)(wave * 32 + 4 * lg);  // + 16 * rs + r
-        const f32x4 rsc0 = *reinterpret_cast<const f32x4*>(rsb + wave * 32 + 4 * lg);
-        const f32x4 rsc1 = *reinterpret_cast<const f32x4*>(rsb + wave * 32 + 16 + 4 * lg);
+        e.par = kLists == 2 ? (unsigned)(ord & 1) : 0u;
+        e.wrow0 = (unsigned)(tile * kTileRows) + (unsigned)(wave * 32);
+        // ONE scale per 32-row block (shadow8_from_rows_kernel), so the wave's rows share it and the pre-test on a pair's
+        // largest accumulator is EXACT at pair level: it passes iff some value of the pair passes.  Rows past the count
+        // carry NaN: the block's first row exists whenever any of its rows does, and the per-value test masks the others.
+        const float rs0 = lds_rs[(ord & 1) * kI8RsStride + wave * 32];
+        e.rsl = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(valid ? rs0 : __builtin_nanf(""))));
+#pragma unroll
+        for (int j = 0; j < NQB / 8; ++j) e.thw[j] = *reinterpret_cast<const u32x4*>(lds_w + (j * 16 + c) * 4);
+        return e;
+    };
+    auto epi_pair = [&](auto QB_, const EpiCtx& e) __attribute__((always_inline)) {
+        constexpr int qb = decltype(QB_)::value;
+        const i32x4 a0 = acc[0][qb], a1 = acc[1][qb];
+        const int m = max(max(max(a0[0], a0[1]), max(a0[2], a0[3])), max(max(a1[0], a1[1]), max(a1[2], a1[3])));
+        // no accumulator of the pair reaches the threshold when the largest one does not (same scale, rounding is
+        // monotone, a non-positive accumulator is below a positive threshold anyway).  The pre-test threshold is the exact one
+        // rounded DOWN to bf16 (two per register: 16 of them cost 8 registers instead of 16 at the point where the program
+        // is tightest); the per-value test below uses the exact one.
+        const unsigned w = e.thw[qb >> 3][(qb >> 1) & 3];
+        const float thp = __uint_as_float((qb & 1) ? (w & 0xffff0000u) : (w << 16));
+        if (__builtin_expect(__any((float)m * e.rsl >= thp), 0)) {
+            int l = lane;
+            asm volatile("" : "+v"(l));  // (lane coordinates derived BEHIND the opaque asm: hipcc otherwise computes them once at kernel start and parks them in scratch)
+            const int c = l & 15, lg = l >> 4;
+            const unsigned q = (unsigned)(qb * 16 + c);
+            const unsigned row0 = e.wrow0 + (unsigned)(4 * lg);  // + 16 * rs + r
+            const float th = __uint_as_float(lds_w[576 + q]);    // the exact threshold (thr / qscale)
+            // Branches are what this path pays for (no prediction: every taken one refills the wave's instruction buffer,
+            // every exec-mask test waits for the compare), so the common case — no lane holds more than one hit among
+            // its 8 rows — runs straight-line: the per-value tests select the lane's hit and count them, one append.
+            auto append = [&](float val, int i) __attribute__((always_inline)) {
+                const unsigned slot = atomicAdd(&lds_w[256 + e.par], 1u);
+                const unsigned row = row0 + (unsigned)(16 * (i >> 2) + (i & 3));
+                if (slot < kListCap) {
+                    unsigned* h = lds_hits + (e.par * kListCap + slot) * 3;
+                    h[0] = __float_as_uint(val);   // (the query's scale is applied by the flush)
+                    h[1] = row;
+                    h[2] = q;
+                }
+#ifndef CODD_I8_EXP_NOGLOBAL  // (diagnostic: hits past a full list are dropped)
+                else {
+                    // workgroup list full (a dense cluster many queries point at, more hits inside one tile than the
+                    // list holds): straight to the query's global list.  Slow (a returning global atomic per hit) but
+                    // complete: the query keeps its candidates and needs no fallback.
+                    const unsigned gslot = atomicAdd(&hit_cnt[q * kHitCntStride], 1u);
+                    if (gslot < (unsigned)cap_q) hits[(int64_t)q * cap_q + gslot] = make_key(val * __uint_as_float(lds_w[320 + q]), row);
+                }
+#endif
+            };
+            float v[8], sv = 0.0f;
+            int si = -1, cnt = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                v[i] = (float)(i < 4 ? a0[i] : a1[i - 4]) * e.rsl;  // the first-generation kernel's expression (its rscale[row] IS the block's scale)
+                const bool h = v[i] >= th && row0 + (unsigned)(16 * (i >> 2) + (i & 3)) < n_rows;
+                sv = h ? v[i] : sv;
+                si = h ? i : si;
+                cnt += h ? 1 : 0;
+            }
+#ifdef CODD_I8_EXP_NOAPPEND
+            asm volatile("" ::"v"(sv), "v"(si), "v"(cnt));  // diagnostic: the per-value test runs, nothing is appended
+#else
+            if (__builtin_expect(__any(cnt > 1), 0)) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (v[i] >= th && row0 + (unsigned)(16 * (i >> 2) + (i & 3)) < n_rows) append(v[i], i);
+            } else if (si >= 0) {
+                append(sv, si);
+            }
+#endif
+        }
+    };
+    auto epilogue = [&](int64_t cu, int ord) __attribute__((always_inline)) {
 #ifdef CODD_I8_EXP_NOEPI
         if (true) {
 #pragma unroll
@@ -263,70 +357,16 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
 #else
         if (MODE == MODE_FILTER) {
 #endif
-            // the lane's 16 pre-test thresholds (queries 16 qb + c) in four reads, and the scale of the wave's 32-row block: the
-            // int8 shadow is quantised with ONE scale per 32-row block (shadow8_from_rows_kernel), so every row of the lane
-            // carries the same value and the maximum below just drops the NaN scales of rows past n.  The pre-test on the
-            // pair's largest accumulator is therefore EXACT at pair level: it passes iff some value of the pair passes.
-            f32x4 thp4[NQB / 4];
-#pragma unroll
-            for (int j = 0; j < NQB / 4; ++j) thp4[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(lds_w) + (j * 16 + c) * 4);
-            const float rsl = fmaxf(fmaxf(fmaxf(rsc0[0], rsc0[1]), fmaxf(rsc0[2], rsc0[3])), fmaxf(fmaxf(rsc1[0], rsc1[1]), fmaxf(rsc1[2], rsc1[3])));
-#pragma unroll
-            for (int qb = 0; qb < NQB; ++qb) {
-                const i32x4 a0 = acc[0][qb], a1 = acc[1][qb];
-                const int m = max(max(max(a0[0], a0[1]), max(a0[2], a0[3])), max(max(a1[0], a1[1]), max(a1[2], a1[3])));
-                // no accumulator of the pair reaches the threshold when the largest one does not (same scale, rounding is
-                // monotone, a non-positive accumulator is below a positive threshold anyway)
-                const float thp = thp4[qb >> 2][qb & 3];
-                if (__builtin_expect(__any((float)m * rsl >= thp), 0)) {
-                    const unsigned q = (unsigned)(qb * 16 + c);
-                    const float th = thp == -INFINITY ? __uint_as_float(lds_w[576 + q]) : thp;  // (the exact threshold when it is not positive)
-                    // Branches are what this path pays for (no prediction: every taken one refills the wave's instruction buffer,
-                    // every exec-mask test waits for the compare), so the common case — no lane holds more than one hit among
-                    // its 8 rows — runs straight-line: the per-value tests select the lane's hit and count them, one append.
-                    auto append = [&](float val, int i) __attribute__((always_inline)) {
-                        const unsigned slot = atomicAdd(&lds_w[256 + par], 1u);
-                        const unsigned row = row0 + (unsigned)(16 * (i >> 2) + (i & 3));
-                        if (slot < kListCap) {
-                            unsigned* e = lds_hits + (par * kListCap + slot) * 3;
-                            e[0] = __float_as_uint(val);   // (the query's scale is applied by the flush)
-                            e[1] = row;
-                            e[2] = q;
-                        }
-#ifndef CODD_I8_EXP_NOGLOBAL  // (diagnostic: hits past a full list are dropped)
-                        else {
-                            // workgroup list full (a dense cluster many queries point at, more hits inside one tile than the
-                            // list holds): straight to the query's global list.  Slow (a returning global atomic per hit) but
-                            // complete: the query keeps its candidates and needs no fallback.
-                            const unsigned gslot = atomicAdd(&hit_cnt[q * kHitCntStride], 1u);
-                            if (gslot < (unsigned)cap_q) hits[(int64_t)q * cap_q + gslot] = make_key(val * __uint_as_float(lds_w[320 + q]), row);
-                        }
-#endif
-                    };
-                    float v[8], sv = 0.0f;
-                    int si = -1, cnt = 0;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        v[i] = (float)(i < 4 ? a0[i] : a1[i - 4]) * (i < 4 ? rsc0[i] : rsc1[i - 4]);  // the first-generation kernel's expression
-                        const bool h = v[i] >= th;
-                        sv = h ? v[i] : sv;
-                        si = h ? i : si;
-                        cnt += h ? 1 : 0;
-                    }
-#ifdef CODD_I8_EXP_NOAPPEND
-                    asm volatile("" ::"v"(sv), "v"(si), "v"(cnt));  // diagnostic: the per-value test runs, nothing is appended
-#else
-                    if (__builtin_expect(__any(cnt > 1), 0)) {
-#pragma unroll
-                        for (int i = 0; i < 8; ++i)
-                            if (v[i] >= th) append(v[i], i);
-                    } else if (si >= 0) {
-                        append(sv, si);
-                    }
-#endif
-                }
-            }
+            const EpiCtx e = epi_begin(cu, ord, true);
+            static_for<NQB>([&](auto QB_) __attribute__((always_inline)) { epi_pair(QB_, e); });
         } else {
+            int c = lane & 15, lg = lane >> 4;
+            asm volatile("" : "+v"(c), "+v"(lg));
+            const int64_t tile = cu * tile_stride;
+            const unsigned par = kLists == 2 ? (unsigned)(ord & 1) : 0u;
+            const float* rsb = lds_rs + (ord & 1) * kI8RsStride;
+            const f32x4 rsc0 = *reinterpret_cast<const f32x4*>(rsb + wave * 32 + 4 * lg);
+            const f32x4 rsc1 = *reinterpret_cast<const f32x4*>(rsb + wave * 32 + 16 + 4 * lg);
             // best (score, row) of the wave's 32 rows per query, folded into the tile's keys in LDS.  The 32 rows share one scale
             // (block-scaled shadow), so the order of their scores is the order of their accumulators: (accumulator, lower row
             // first) packs into one int — |accumulator| <= 127 * 127 * 4096 < 2^26, five bits for the row — and the fold across
@@ -384,13 +424,21 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             lds_read_b128_asm<(((g % NQB) * 2) + (g / NQB)) * 1024>(b[g], qaddr);
         });
     };
-    auto mfma_step = [&](auto SLOT, auto FIRST, i32x4(&b)[kBD], unsigned qaddr) __attribute__((always_inline)) {
+    // FUSED: the first K-step of a tile also carries the PREVIOUS tile's epilogue — pair qb is tested right in front of the
+    // MFMAs that restart its accumulators from zero (K half 0, query block qb)
+    auto mfma_step = [&](auto SLOT, auto FIRST, auto FUSED, i32x4(&b)[kBD], unsigned qaddr, const EpiCtx* ectx) __attribute__((always_inline)) {
         constexpr int slot = decltype(SLOT)::value;
         constexpr bool first = decltype(FIRST)::value;
+        constexpr bool fused = decltype(FUSED)::value;
+        static_assert(!fused || first, "the fused epilogue belongs to a tile's first K-step");
         constexpr int kGroups = 2 * NQB;  // (K half, query block) groups of 2 MFMAs per K-step
         static_for<kGroups>([&](auto G_) __attribute__((always_inline)) {
             constexpr int g = decltype(G_)::value, ks = g / NQB, qb = g % NQB;
             constexpr int younger = (g + kBD - 1 < kGroups - 1 ? g + kBD - 1 : kGroups - 1) - g;
+            if constexpr (fused && ks == 0) {
+                epi_pair(std::integral_constant<int, qb>{}, *ectx);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             lgkm_wait_asm<younger>(b[g % kBD]);
             const i32x4 a0 = __builtin_bit_cast(i32x4, ring[slot][0 * 2 + ks]);
             const i32x4 a1 = __builtin_bit_cast(i32x4, ring[slot][1 * 2 + ks]);
@@ -441,7 +489,10 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         // (the generic loop); the tile-structured loop below runs it between intervals instead.
         // (A loop that is not unrolled, with a uniform switch around three static copies of [loads, wait, MFMAs], made
         // hipcc merge the 128 accumulator registers across the arms with copies: 700 bytes of scratch.)
-        auto interval = [&](auto IU, auto EPI, auto FIRST, int t) __attribute__((always_inline)) {
+        // BOOK: the interval may be a tile's second one (w_s == 1), behind whose barrier the workgroup's bookkeeping runs (hit-list
+        // flush, sample keys): the tile-structured program knows statically which of its unrolled intervals that is, and the
+        // flush code — 2 KB, with a handful of loop-invariant registers hipcc hoists out of the loop — exists once instead of six times
+        auto interval = [&](auto IU, auto EPI, auto FIRST, auto FUSED, auto BOOK, int t, const EpiCtx* ectx) __attribute__((always_inline)) {
             constexpr int iu = decltype(IU)::value;
             constexpr int ci = (iu + 3 - LAG) % 3, li = (ci + 2) % 3;
             if (decltype(EPI)::value && pending) {
@@ -461,7 +512,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             i8_wait_vm<2 * kOpsPerIv>(ring[ci][0], ring[ci][1], ring[ci][2], ring[ci][3]);
             __builtin_amdgcn_sched_barrier(0);
             if (!CODD_I8_EARLY_FRAGS) frag_prefetch(b, qaddr);
-            mfma_step(std::integral_constant<int, ci>{}, FIRST, b, qaddr);
+            mfma_step(std::integral_constant<int, ci>{}, FIRST, FUSED, b, qaddr, ectx);
             const int s = t - LAG;
             if (s >= 0) {
                 if (s < T && c_s == nsteps - 1) { pending = true; p_u = c_u; p_ord = c_ord; }
@@ -478,14 +529,16 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             // every wave has folded tile w_ord - 1 when the barrier of the interval with w_s == 1 releases, and no wave
             // writes that tile's half of the shared state again before the barrier inside the next tile (staged program:
             // no epilogue runs in the next interval, nsteps >= 3): the counters read here are stable
-            if (w_s == 1 && w_ord >= 1) {
+            if (decltype(BOOK)::value && w_s == 1 && w_ord >= 1) {
                 const unsigned par = kLists == 2 ? (unsigned)((w_ord - 1) & 1) : 0u;
                 if (MODE == MODE_FILTER) {
                     const unsigned cnt = lds_w[256 + par];
                     if (cnt > (kLists == 2 ? kListCap / 2 : (unsigned)(CODD_FLUSH_AT))) {
                         // (per-query ranges reserved with one global atomic each: on clustered corpora a tile fills the list
                         // and every workgroup flushes every tile; one atomic per hit serialises on 256 counters)
-                        flush_hits_binned(lds_hits + par * kListCap * 3, cnt < kListCap ? cnt : kListCap, tid, lds_w + 832, hits, hit_cnt, cap_q, reinterpret_cast<const float*>(lds_w + 320));
+                        int tid_f = tid;
+                        asm volatile("" : "+v"(tid_f));  // (or hipcc hoists &hit_cnt[tid] out of the tile loop and parks the pointer in scratch)
+                        flush_hits_binned(lds_hits + par * kListCap * 3, cnt < kListCap ? cnt : kListCap, tid_f, lds_w + 832, hits, hit_cnt, cap_q, reinterpret_cast<const float*>(lds_w + 320));
                         __syncthreads();
                         if (tid == 0) lds_w[256 + par] = 0u;
                     }
@@ -506,28 +559,38 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             // epilogue sits BETWEEN the unrolled intervals and exists once in the program instead of three times (the
             // inlined copies, each 19 KB of code run once per tile, kept missing the instruction cache)
             int t = 0;
+            constexpr bool kFuse = CODD_I8_FUSE_EPI && MODE == MODE_FILTER;
+            const std::integral_constant<bool, kFuse> fuse{};
+            const std::false_type no{};
             for (int64_t o = 0; o < my_tiles; ++o) {
-                if (pending) {
+                EpiCtx ectx;
+                if constexpr (kFuse) {
+                    // tile o - 1 (this workgroup's previous one) is tested inside the first K-step below; the first tile has
+                    // nothing behind it: the same code runs on NaN scales, which fail every comparison
+                    ectx = epi_begin(pending ? p_u : c_u, pending ? p_ord : 0, pending);
+                    pending = false;
+                } else if (pending) {
                     epilogue(p_u, p_ord);
                     pending = false;
                 }
                 // the tile's first K-step starts its accumulators from zero: no clearing pass in the epilogue
-                interval(std::integral_constant<int, 0>{}, std::false_type{}, std::true_type{}, t);
-                interval(std::integral_constant<int, 1>{}, std::false_type{}, std::false_type{}, t + 1);
-                interval(std::integral_constant<int, 2>{}, std::false_type{}, std::false_type{}, t + 2);
+                interval(std::integral_constant<int, 0>{}, no, std::true_type{}, fuse, no, t, &ectx);
+                interval(std::integral_constant<int, 1>{}, no, no, no, std::true_type{}, t + 1, nullptr);   // (w_s == 1: the bookkeeping)
+                interval(std::integral_constant<int, 2>{}, no, no, no, no, t + 2, nullptr);
                 t += 3;
                 for (int s3 = 3; s3 < nsteps; s3 += 3) {
-                    interval(std::integral_constant<int, 0>{}, std::false_type{}, std::false_type{}, t);
-                    interval(std::integral_constant<int, 1>{}, std::false_type{}, std::false_type{}, t + 1);
-                    interval(std::integral_constant<int, 2>{}, std::false_type{}, std::false_type{}, t + 2);
+                    interval(std::integral_constant<int, 0>{}, no, no, no, no, t, nullptr);
+                    interval(std::integral_constant<int, 1>{}, no, no, no, no, t + 1, nullptr);
+                    interval(std::integral_constant<int, 2>{}, no, no, no, no, t + 2, nullptr);
                     t += 3;
                 }
             }
         } else {
+            const std::false_type no{};
             for (int t0 = 0; t0 < TI; t0 += 3) {
-                interval(std::integral_constant<int, 0>{}, std::true_type{}, std::false_type{}, t0);
-                interval(std::integral_constant<int, 1>{}, std::true_type{}, std::false_type{}, t0 + 1);
-                interval(std::integral_constant<int, 2>{}, std::true_type{}, std::false_type{}, t0 + 2);
+                interval(std::integral_constant<int, 0>{}, std::true_type{}, no, no, std::true_type{}, t0, nullptr);
+                interval(std::integral_constant<int, 1>{}, std::true_type{}, no, no, std::true_type{}, t0 + 1, nullptr);
+                interval(std::integral_constant<int, 2>{}, std::true_type{}, no, no, std::true_type{}, t0 + 2, nullptr);
             }
         }
         // The corpus loads of the last two intervals are never consumed: hipcc considers their destination registers free

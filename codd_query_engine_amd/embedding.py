@@ -34,23 +34,45 @@ class HashingEmbeddingFunction:
             raise ValueError("dim must be >= 8")
         self.dim = int(dim)
         self.trigram_weight = float(trigram_weight)
+        self._cache: dict = {}
+        self._cache_max = 1 << 18   # tokens remembered (a few tens of MB at most)
 
     def _bucket(self, feature: str) -> int:
         return zlib.crc32(feature.encode("utf-8")) % self.dim
 
-    def embed_one(self, text: str) -> np.ndarray:
-        v = np.zeros(self.dim, dtype=np.float32)
-        for tok in _TOKEN.findall(text.lower()):
-            v[self._bucket("w:" + tok)] += 1.0
+    def _token_features(self, tok: str):
+        """(buckets, weights) of one lower-cased token: its word feature, then its character trigrams, in that order.
+        Cached: metric vocabularies repeat their tokens thousands of times, and hashing (encode + crc32 per feature, a
+        Python-level loop) was most of a query's host time (bench.py `dropin_call`)."""
+        hit = self._cache.get(tok)
+        if hit is None:
             padded = f"^{tok}$"
-            for i in range(len(padded) - 2):
-                v[self._bucket("t:" + padded[i : i + 3])] += self.trigram_weight
-        return v
+            buckets = [self._bucket("w:" + tok)] + [self._bucket("t:" + padded[i : i + 3]) for i in range(len(padded) - 2)]
+            weights = np.full(len(buckets), self.trigram_weight, dtype=np.float32)
+            weights[0] = 1.0
+            hit = (np.asarray(buckets, dtype=np.intp), weights)
+            if len(self._cache) < self._cache_max:
+                self._cache[tok] = hit
+        return hit
+
+    def embed_one(self, text: str) -> np.ndarray:
+        return self([text])[0]
 
     def __call__(self, texts: Sequence[str]) -> np.ndarray:
-        if len(texts) == 0:
-            return np.zeros((0, self.dim), dtype=np.float32)
-        return np.stack([self.embed_one(t) for t in texts]).astype(np.float32)
+        out = np.zeros((len(texts), self.dim), dtype=np.float32)
+        idx, wts, rows = [], [], []
+        for r, text in enumerate(texts):
+            for tok in _TOKEN.findall(text.lower()):
+                b, w = self._token_features(tok)
+                idx.append(b)
+                wts.append(w)
+                rows.append((r, len(b)))
+        if idx:
+            # one unbuffered, in-order float32 accumulation for the whole batch: each bucket receives its additions in text
+            # order, i.e. the same bits as the feature-by-feature loop this replaces
+            flat = np.concatenate(idx) + np.repeat(np.asarray([r for r, _ in rows], dtype=np.intp) * self.dim, [m for _, m in rows])
+            np.add.at(out.reshape(-1), flat, np.concatenate(wts))
+        return out
 
 
 class LocalTransformerEmbeddingFunction:

@@ -296,65 +296,98 @@ class MetricsSemanticIndexerJob:
         prepare = getattr(self.semantic_store, "prepare_index", None)
         commit = getattr(self.semantic_store, "commit_index", None)
         two_phase = callable(prepare) and callable(commit)
-        prepared: list = []
-        for item in batch:
-            name = item["metric"]
-            mtype = item.get("type", "unknown")
-            help_text = item.get("help", "")
-            try:
-                if dry_run:
+        # Two-phase: a metric's outcome is only known once the batch's upsert has run, so the batch's report lines are
+        # collected and printed behind it — the same bytes in the same order as the reference prints them one by one, with
+        # exactly ONE outcome (✓ or ✗) per metric and `indexed_metrics` counting what was actually stored, also when the
+        # upsert fails or the job is interrupted between prepare and commit.
+        report: list[str] = []                      # the batch's output, in order (two-phase only)
+        pending: list[tuple[int, Any, str]] = []    # (position in `report`, prepared record, its success suffix)
+        failed_at: dict[int, BaseException] = {}
+        committed = False
+
+        def emit(text: str, end: str = "\n") -> None:
+            if two_phase and not dry_run:
+                report.append(text + end)
+            else:
+                print(text, end=end, flush=(end == ""))
+
+        try:
+            for item in batch:
+                name = item["metric"]
+                mtype = item.get("type", "unknown")
+                help_text = item.get("help", "")
+                try:
+                    if dry_run:
+                        self.stats.processed_metrics += 1
+                        preview = help_text[:60] + "..." if len(help_text) > 60 else help_text
+                        emit(f"        → {name} (type: {mtype}, desc: {preview or 'N/A'})")
+                        continue
+                    if skip_if_present and self.semantic_store.metric_exists(namespace, name):
+                        self.stats.skipped_metrics += 1
+                        emit(f"        → Skipping: {name} (already present)")
+                        continue
                     self.stats.processed_metrics += 1
-                    preview = help_text[:60] + "..." if len(help_text) > 60 else help_text
-                    print(f"        → {name} (type: {mtype}, desc: {preview or 'N/A'})")
-                    continue
-                if skip_if_present and self.semantic_store.metric_exists(namespace, name):
-                    self.stats.skipped_metrics += 1
-                    print(f"        → Skipping: {name} (already present)")
-                    continue
-                self.stats.processed_metrics += 1
-                print(f"        → Enriching: {name}", end="", flush=True)
-                enriched = self.enrichment_agent.enrich_metric_to_dict(
-                    metric_name=name, metric_type=mtype, description=help_text if help_text else None
-                )
-                self.stats.enriched_metrics += 1
-                if two_phase:
-                    prepared.append(prepare(namespace, enriched))
-                else:
+                    emit(f"        → Enriching: {name}", end="")
+                    enriched = self.enrichment_agent.enrich_metric_to_dict(
+                        metric_name=name, metric_type=mtype, description=help_text if help_text else None
+                    )
+                    self.stats.enriched_metrics += 1
+                    done = (
+                        f" ✓ (category: {enriched.get('category', 'N/A')}, "
+                        f"signal: {enriched.get('golden_signal_type', 'N/A')}, "
+                        f"meter_type: {enriched.get('meter_type', 'N/A')})"
+                    )
+                    if two_phase:
+                        record = prepare(namespace, enriched)   # validates and composes here: same exceptions, same place
+                        report.append("")                       # the metric's outcome, filled in behind the upsert
+                        pending.append((len(report) - 1, record, done))
+                        continue
                     self.semantic_store.index_metadata(namespace, enriched)
-                self.stats.indexed_metrics += 1
-                print(
-                    f" ✓ (category: {enriched.get('category', 'N/A')}, "
-                    f"signal: {enriched.get('golden_signal_type', 'N/A')}, "
-                    f"meter_type: {enriched.get('meter_type', 'N/A')})"
-                )
-            except Exception as exc:
-                self.stats.failed_metrics += 1
-                if type(exc).__name__ == "MetricEnrichmentError":  # ours or a caller agent's own class
-                    print(f" ✗ (enrichment failed: {str(exc)[:50]}...)")
-                    logger.warning(f"Failed to enrich metric: {name}")
+                    self.stats.indexed_metrics += 1
+                    print(done)
+                except Exception as exc:
+                    self.stats.failed_metrics += 1
+                    if type(exc).__name__ == "MetricEnrichmentError":  # ours or a caller agent's own class
+                        emit(f" ✗ (enrichment failed: {str(exc)[:50]}...)")
+                        logger.warning(f"Failed to enrich metric: {name}")
+                    else:
+                        emit(f" ✗ (error: {str(exc)[:50]}...)")
+                        logger.error(f"Failed to process metric: {name}", exc_info=True)
+            if pending:
+                failed_at = self._commit_batch([rec for _, rec, _ in pending], commit)
+            committed = True
+        finally:
+            # (also on KeyboardInterrupt / SystemExit between prepare and commit: nothing is reported as indexed that was not)
+            for j, (pos, rec, done) in enumerate(pending):
+                if committed and j not in failed_at:
+                    self.stats.indexed_metrics += 1
+                    report[pos] = done + "\n"
+                elif j in failed_at:
+                    self.stats.failed_metrics += 1
+                    report[pos] = f" ✗ (error: {str(failed_at[j])[:50]}...)\n"
+                    logger.error(f"Failed to index metric: {rec[0]}: {failed_at[j]}")
                 else:
-                    print(f" ✗ (error: {str(exc)[:50]}...)")
-                    logger.error(f"Failed to process metric: {name}", exc_info=True)
-        if prepared:
-            self._commit_batch(prepared, commit)
+                    report[pos] = " ✗ (interrupted before the batch was stored)\n"
+            if report:
+                print("".join(report), end="", flush=True)
         print()
 
-    def _commit_batch(self, prepared: list, commit: Callable[[list], Any]) -> None:
+    def _commit_batch(self, prepared: list, commit: Callable[[list], Any]) -> dict:
         """One upsert for the batch.  If the store rejects it as a whole (a device error, not a validation error: those
-        were raised per metric above), the metrics are retried one by one so that the counters name the ones that failed."""
+        were raised per metric above), the metrics are retried one by one so that the report names the ones that failed.
+        Returns {position in `prepared`: exception} for the metrics that could not be stored."""
         try:
             commit(prepared)
-            return
+            return {}
         except Exception as exc:
             logger.error(f"Batched upsert of {len(prepared)} metrics failed ({exc}); retrying one by one")
-        for one in prepared:
+        failed: dict = {}
+        for j, one in enumerate(prepared):
             try:
                 commit([one])
             except Exception as exc:
-                self.stats.indexed_metrics -= 1
-                self.stats.failed_metrics += 1
-                print(f"        ✗ {one[0]} (error: {str(exc)[:50]}...)")
-                logger.error(f"Failed to index metric: {one[0]}", exc_info=True)
+                failed[j] = exc
+        return failed
 
     def _print_summary(self) -> None:
         s = self.stats

@@ -162,7 +162,7 @@ int codd_knn_approx_scores(codd_knn_index* index, const float* dev_queries, int 
  * over those lists, top-k with ORIGINAL row slots; with nprobe == nlist the result is bit-identical
  * to codd_knn_search.  Any of dev_keys / dev_dist / dev_rows may be NULL.
  */
-int codd_knn_copy_rows_f32(const codd_knn_index* index, int64_t first, int64_t n, float* dev_out, void* stream);
+int codd_knn_copy_rows_f32(codd_knn_index* index, int64_t first, int64_t n, float* dev_out, void* stream);
 int codd_knn_ivf_install(codd_knn_index* index, const float* dev_centroids, int nlist,
                          const int64_t* dev_perm, const int64_t* dev_offsets, void* stream);
 int codd_knn_ivf_search(codd_knn_index* index, const float* dev_queries, int B, int k, int nprobe,

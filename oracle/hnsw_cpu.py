@@ -18,7 +18,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "libhnsw_cpu.so")
+# CODD_ORACLE_LIB_DIR: load the library from another build directory (oracle/Makefile `asan-test`: the sanitizer build)
+_LIB_PATH = os.path.join(os.environ.get("CODD_ORACLE_LIB_DIR") or os.path.join(_HERE, "_build"), "libhnsw_cpu.so")
 REFERENCE_PARAMS = {"M": 16, "construction_ef": 200, "search_ef": 100}  # store.py:63-68
 
 _lib = None

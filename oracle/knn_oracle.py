@@ -26,7 +26,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "libknn_oracle.so")
+# CODD_ORACLE_LIB_DIR: load the library from another build directory (oracle/Makefile `asan-test`: the sanitizer build)
+_LIB_PATH = os.path.join(os.environ.get("CODD_ORACLE_LIB_DIR") or os.path.join(_HERE, "_build"), "libknn_oracle.so")
 
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 _DT_BY_NAME = {"f32": DT_F32, "bf16": DT_BF16, "f16": DT_F16}

@@ -13,7 +13,8 @@ VARIANTS = {
     "noappend": {"CODD_I8_EXP_NOAPPEND": 1},
     "noflush": {"CODD_I8_EXP_NOFLUSH": 1},
     "noglobal": {"CODD_I8_EXP_NOGLOBAL": 1},
-    "latefrags": {"CODD_I8_EARLY_FRAGS": 0},
+    "latefrags": {"CODD_I8_EARLY_FRAGS": 0, "CODD_EXPERIMENTS": 1},
+    "nofuse": {"CODD_I8_FUSE_EPI": 0},  # round 3: the epilogue as a block of its own between tiles (round 2's placement)
 }
 
 

@@ -163,3 +163,45 @@ def test_real_store_is_fed_one_upsert_per_batch():
     assert job.stats.indexed_metrics == 5 and job.stats.failed_metrics == 1 and job.stats.enriched_metrics == 6
     assert "→ Enriching: bad name! ✗ (error: metric_name contains invalid characters" in out.getvalue()
     assert job.semantic_store.collection.count() == 5
+
+
+def test_a_failing_commit_reports_one_outcome_per_metric():
+    """with the two-phase ingest the ✓ line used to be printed (and indexed_metrics incremented) before the batch was
+    stored; a metric whose upsert then failed showed ✓ and a separate ✗.  The reference prints exactly one outcome per metric
+    at that position (job.py:409-459)."""
+    class FlakyEngine(OracleEngine):
+        def upsert(self, slots, vecs, normalize=True):
+            if len(slots) > 1:
+                raise RuntimeError("device lost during the batched upsert")       # the batch as a whole is rejected ...
+            if FlakyEngine.calls == 1:
+                FlakyEngine.calls += 1
+                raise RuntimeError("HBM error on this row")                        # ... and one of its metrics again on the retry
+            FlakyEngine.calls += 1
+            return super().upsert(slots, vecs, normalize)
+    FlakyEngine.calls = 0
+
+    client = KnnClient(engine_factory=lambda dim: FlakyEngine(dim))
+    job = MetricsSemanticIndexerJob(None, client, None, None, None, batch_size=3, metadata_source=lambda cfg: StaticMetadataSource(dict(list(PROM.items())[:3])))
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        job.run("prod:api")
+    text = out.getvalue()
+    lines = [l for l in text.splitlines() if "→ Enriching:" in l]
+    assert len(lines) == 3 and all((" ✓ " in l) != (" ✗ " in l) for l in lines), text     # one outcome each, on the metric's own line
+    assert sum(" ✗ (error: HBM error on this row" in l for l in lines) == 1
+    assert job.stats.indexed_metrics == 2 and job.stats.failed_metrics == 1 and job.stats.enriched_metrics == 3
+    assert job.semantic_store.collection.count() == 2
+
+
+def test_an_interrupt_between_prepare_and_commit_counts_nothing_as_indexed():
+    class Interrupting(OracleEngine):
+        def upsert(self, slots, vecs, normalize=True):
+            raise KeyboardInterrupt()
+
+    client = KnnClient(engine_factory=lambda dim: Interrupting(dim))
+    job = MetricsSemanticIndexerJob(None, client, None, None, None, batch_size=2, metadata_source=lambda cfg: StaticMetadataSource(PROM))
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out), pytest.raises(KeyboardInterrupt):
+        job.run("prod:api")
+    assert job.stats.indexed_metrics == 0 and job.stats.enriched_metrics == 2
+    assert out.getvalue().count("✗ (interrupted before the batch was stored)") == 2 and " ✓ (category" not in out.getvalue()

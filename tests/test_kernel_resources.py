@@ -31,10 +31,10 @@ def test_hot_kernels_do_not_spill():
     tile = [name for name in rows if "i8_tile_kernel" in name]
     assert len(tile) == 12, report  # filter (3-step-multiple rows / others) and sample, for 16 and for 8 query blocks, staged and resident slices
     for name in tile:
-        # the staged programs (the headline kernel among them) must not touch scratch; a resident instantiation may park a
-        # few registers of loop invariants (one 64-bit pointer today, reloaded once per interval: measured faster than staged)
-        resident = name.rstrip(">").endswith("true")
-        assert rows[name]["occ"] >= 2 and rows[name]["scratch"] <= (32 if resident else 0), f"{name}:\n{report}"
+        # NO instantiation may touch scratch: the kernel issues its corpus loads and LDS-DMA by inline asm that hipcc cannot see
+        # as in flight, so a ring[] / b[] register spilled between its load and the counted s_waitcnt would store stale bytes —
+        # neighbours silently dropped; and a reload inside the loop waits vmcnt(0), draining the prefetch
+        assert rows[name]["occ"] >= 2 and rows[name]["scratch"] == 0 and rows[name]["spill"] == 0, f"{name}:\n{report}"
     full = next(name for name in rows if "gemm_filter_kernel<0, 8, 0, 0>" in name)
     int8 = next(name for name in rows if "gemm_filter_kernel<0, 1, 1, 0>" in name)  # the single-query latency kernel (int8 shadow)
     assert rows[int8]["occ"] >= 2, report
