@@ -181,14 +181,30 @@ def cpu_baseline(ix, args, queries_cpu):
         hx = hnsw_cpu.HnswIndex(rows[:n_h])
         build_s = time.perf_counter() - t3
         hx.search(qn[:8], args.k)
+        _, exact_ids = o.search_fast_f32(rows[:n_h], qn, args.k)
+        # A throughput figure only means something next to its recall: on the isotropic headline corpus the reference's
+        # search_ef = 100 finds one true neighbour in ten.  `value` is therefore the rate AT MATCHED QUALITY — search_ef doubled
+        # until recall@10 >= 0.95 (capped at the sample size = exhaustive) — and the reference-parameter point is kept as an
+        # observation of recall, not as a speed.
         t3 = time.perf_counter()
         _, ids = hx.search(qn, args.k)
-        dt_h = time.perf_counter() - t3
-        _, exact_ids = o.search_fast_f32(rows[:n_h], qn, args.k)
-        hn = {"kind": "hnsw-restatement", "value": nq / dt_h, "unit": "queries/s", "recall_at_10": hnsw_cpu.recall_at_k(ids, exact_ids),
+        dt_ref = time.perf_counter() - t3
+        at_ref = {"search_ef": hnsw_cpu.REFERENCE_PARAMS["search_ef"], "queries_per_s": nq / dt_ref, "recall_at_10": hnsw_cpu.recall_at_k(ids, exact_ids)}
+        ef, rec, dt_h = at_ref["search_ef"], at_ref["recall_at_10"], dt_ref
+        t_budget = time.perf_counter()
+        while rec < 0.95 and ef < n_h and time.perf_counter() - t_budget < 20.0:
+            ef = min(2 * ef, n_h)
+            t3 = time.perf_counter()
+            _, ids = hx.search(qn, args.k, search_ef=ef)
+            dt_h = time.perf_counter() - t3
+            rec = hnsw_cpu.recall_at_k(ids, exact_ids)
+        hn = {"kind": "hnsw-restatement (unpinned: a from-scratch restatement of the published algorithm, not hnswlib)",
+              "value": nq / dt_h if rec >= 0.95 else None, "unit": "queries/s", "recall_at_10": rec, "search_ef": ef,
+              "matched_quality": rec >= 0.95, "at_reference_search_ef": at_ref,
               "cores": o.num_threads(), "rows": n_h, "build_s": build_s, "params": hnsw_cpu.REFERENCE_PARAMS,
-              "what": f"oracle/hnsw_cpu.c (published algorithm, the reference's parameters) over the first {n_h} rows of the same corpus, {nq} queries; "
-                      "NOT scaled to the full corpus (graph search cost grows ~log N); recall@10 against the exact answer on the same rows"}
+              "what": f"oracle/hnsw_cpu.c (M 16, construction_ef 200 as the reference, store.py:63-68) over the first {n_h} rows of the same corpus, {nq} queries; "
+                      "`value` = queries/s at the smallest doubled search_ef whose recall@10 against the exact answer on the same rows reaches 0.95 "
+                      "(null when 20 s of doubling did not get there); NOT scaled to the full corpus (graph search cost grows ~log N)"}
         hx.close()
     except Exception as e:  # noqa: BLE001
         hn = {"kind": "hnsw-restatement", "value": None, "what": f"failed: {e}"}

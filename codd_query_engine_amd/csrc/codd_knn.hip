@@ -180,27 +180,24 @@ __global__ __launch_bounds__(256) void shadow_from_rows_kernel(const void* __res
 //   - per block: the 4 wave lists are merged through LDS and written as k packed keys to
 //     partial[q][block][0..k).
 // ---------------------------------------------------------------------------------------------
-template <int DT, int NB, int NITER, int SLOTS>
-__global__ __launch_bounds__(256) void scan_topk_kernel(const void* __restrict__ rows_, int64_t n, int dpad,
-                                                        const float* __restrict__ qn, int nq_arg, int k,
-                                                        uint32_t row_base, u64* __restrict__ partial,
-                                                        int64_t partial_stride_q, const unsigned* __restrict__ qlist,
-                                                        const unsigned* __restrict__ qcount_ptr, unsigned* __restrict__ merge_done = nullptr,
-                                                        u64* __restrict__ merged_keys = nullptr, float* __restrict__ merged_dist = nullptr,
-                                                        int64_t* __restrict__ merged_rows = nullptr,
-                                                        unsigned long long* __restrict__ count_total = nullptr) {
+// scan_topk_body: the scan as a workgroup of NW waves sees it — workgroup `bid` of `nblocks`, lds = NW * NB * SLOTS * 64 u64.
+// `total` queries, dense from qn (qlist == nullptr) or listed (qlist[i] = query slot; `listed` also selects the one-launch
+// hand-off to the last block, see below).  Shared by scan_topk_kernel and by the scan role of finalize_fb_kernel.
+template <int DT, int NB, int NITER, int SLOTS, int NW>
+__device__ __forceinline__ void scan_topk_body(const void* __restrict__ rows_, int64_t n, int dpad, const float* __restrict__ qn, int total, int k,
+                                               uint32_t row_base, u64* __restrict__ partial, int64_t partial_stride_q,
+                                               const unsigned* __restrict__ qlist, bool listed, unsigned* __restrict__ merge_done,
+                                               u64* __restrict__ merged_keys, float* __restrict__ merged_dist, int64_t* __restrict__ merged_rows,
+                                               unsigned long long* __restrict__ count_total, int bid, int nblocks, u64* __restrict__ lds) {
     typedef RowTraits<DT> RT;
     constexpr int E = RT::E;
     const int lane = lane_id();
     const int wave = (int)(threadIdx.x >> 6);
     const int nchunks = dpad / E;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    u64* lds = reinterpret_cast<u64*>(smem_raw);
 
     // Two ways in: (a) the host names a dense group of nq_arg <= NB queries starting at qn (one pass);
     // (b) LISTED: qcount_ptr / qlist live on the device (the filter's fallback queue) and the kernel walks
     // the queue NB queries at a time — zero queued queries is the common case and costs one empty launch.
-    const int total = qcount_ptr ? (int)*qcount_ptr : nq_arg;
     for (int g0 = 0; g0 < total; g0 += NB) {
     const int nq = total - g0 < NB ? total - g0 : NB;
 
@@ -223,8 +220,8 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const void* __restrict__
 
     const uint4* base = reinterpret_cast<const uint4*>(rows_);
     const int64_t ngroups = (n + 3) >> 2;
-    const int64_t W = (int64_t)gridDim.x * 4;
-    for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < ngroups; g += W) {
+    const int64_t W = (int64_t)nblocks * NW;
+    for (int64_t g = (int64_t)bid * NW + wave; g < ngroups; g += W) {
         float w[4][NITER][E];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -266,17 +263,17 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const void* __restrict__
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) lds[((wave * NB + b) * SLOTS + s) * kWave + lane] = L[b].v[s];
     __syncthreads();
-    for (int b = wave; b < nq; b += 4) {
+    for (int b = wave; b < nq; b += NW) {
         WaveTopK<SLOTS> M;
         M.init();
-        for (int wv = 0; wv < 4; ++wv)
+        for (int wv = 0; wv < NW; ++wv)
 #pragma unroll
             for (int s = 0; s < SLOTS; ++s) {
                 u64 cand = lds[((wv * NB + b) * SLOTS + s) * kWave + lane];
                 if (s * kWave + lane >= k) cand = 0ull;
                 M.offer_lanes(cand, k, lane);
             }
-        u64* dst = partial + (int64_t)(g0 + b) * partial_stride_q + (int64_t)blockIdx.x * k;
+        u64* dst = partial + (int64_t)(g0 + b) * partial_stride_q + (int64_t)bid * k;
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
             const int rank = s * kWave + lane;
@@ -290,17 +287,18 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const void* __restrict__
     // the answers into the queries' own slots — the fallback is ONE launch (an empty queue, the normal case, costs one
     // empty launch and touches no counter).  Hand-off: every block's stores, a device-scope fence, the arrival ticket;
     // the last arriver fences again before it reads the other blocks' partials.
-    if (qcount_ptr && merge_done && total > 0) {
+    if (listed && merge_done && total > 0) {
         __shared__ unsigned s_last;
         __threadfence();
         __syncthreads();
-        if (threadIdx.x == 0) s_last = atomicAdd(merge_done, 1u) == gridDim.x - 1 ? 1u : 0u;
+        if (threadIdx.x == 0) s_last = atomicAdd(merge_done, 1u) == (unsigned)nblocks - 1u ? 1u : 0u;
         __syncthreads();
         if (!s_last) return;
         __threadfence();
+        if (threadIdx.x == 0) *merge_done = 0u;  // (ready for the next list-driven launch without a clearing pass)
         if (threadIdx.x == 0 && count_total) atomicAdd(count_total, (unsigned long long)total);
-        const int64_t m = (int64_t)gridDim.x * k;
-        for (int qi = wave; qi < total; qi += 4) {
+        const int64_t m = (int64_t)nblocks * k;
+        for (int qi = wave; qi < total; qi += NW) {
             const u64* src = partial + (int64_t)qi * partial_stride_q;
             WaveTopK<SLOTS> M;
             M.init();
@@ -321,6 +319,77 @@ __global__ __launch_bounds__(256) void scan_topk_kernel(const void* __restrict__
             }
         }
     }
+}
+
+template <int DT, int NB, int NITER, int SLOTS>
+__global__ __launch_bounds__(256) void scan_topk_kernel(const void* __restrict__ rows_, int64_t n, int dpad,
+                                                        const float* __restrict__ qn, int nq_arg, int k,
+                                                        uint32_t row_base, u64* __restrict__ partial,
+                                                        int64_t partial_stride_q, const unsigned* __restrict__ qlist,
+                                                        const unsigned* __restrict__ qcount_ptr, unsigned* __restrict__ merge_done = nullptr,
+                                                        u64* __restrict__ merged_keys = nullptr, float* __restrict__ merged_dist = nullptr,
+                                                        int64_t* __restrict__ merged_rows = nullptr,
+                                                        unsigned long long* __restrict__ count_total = nullptr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int total = qcount_ptr ? (int)*qcount_ptr : nq_arg;
+    scan_topk_body<DT, NB, NITER, SLOTS, 4>(rows_, n, dpad, qn, total, k, row_base, partial, partial_stride_q, qlist, qcount_ptr != nullptr, merge_done, merged_keys,
+                                            merged_dist, merged_rows, count_total, (int)blockIdx.x, (int)gridDim.x, reinterpret_cast<u64*>(smem_raw));
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize_fb_kernel: finalize and the exact-scan fallback of a filter pass in ONE launch (round 3: the fallback used to be a
+// launch of its own behind finalize — normally empty, still 4 us + a dependent-launch gap of ~10 us on every step).
+//   workgroups x < nq  : finalize_kernel's work for query x (share blockIdx.y of its candidates);
+//   workgroups x >= nq : the exact scan over the queries whose candidate lists were truncated (hit_cnt > cap_q).  They need
+//     nothing from the finalize workgroups: each derives the queue from the counters itself (same order in every workgroup)
+//     and leaves at once when it is empty — the normal case.  Otherwise: scan_topk_body over the queue, the last scan
+//     workgroup to finish merges the per-workgroup partials and writes the answers into the queries' slots.
+// k <= 64 only (one list slot per lane); wider k keeps the two launches.
+// ---------------------------------------------------------------------------------------------
+template <int DT, int NITER>
+__global__ __launch_bounds__(kFinThreads) void finalize_fb_kernel(const void* __restrict__ rows_, int dpad, const float* __restrict__ qn, const u64* __restrict__ hits,
+                                                                   const unsigned* __restrict__ hit_cnt, int cap_q, unsigned* __restrict__ flags, int k, float two_eps,
+                                                                   uint32_t row_base, u64* __restrict__ out_keys, unsigned long long* __restrict__ stats,
+                                                                   const float* __restrict__ two_eps_q, u64* __restrict__ part_keys, float* __restrict__ out_dist,
+                                                                   int64_t* __restrict__ out_rows, const float2* __restrict__ bmeta, int nq, int64_t n,
+                                                                   u64* __restrict__ fb_partial, int64_t fb_stride_q, unsigned* __restrict__ fb_done) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int kWavesHere = kFinThreads / kWave;
+    if ((int)blockIdx.x < nq) {
+        const int q = blockIdx.x;
+        const unsigned total = hit_cnt[q * kHitCntStride];
+        const unsigned part = blockIdx.y, nparts = gridDim.y;
+        if (total > (unsigned)cap_q) {  // the candidate list was truncated: the scan workgroups answer this query
+            if (threadIdx.x == 0 && part == 0) atomicOr(&flags[FLAG_NEED_FALLBACK], 1u);
+            return;
+        }
+        const float eps1 = bmeta ? two_eps_q[256 + q] : 0.5f * (two_eps_q ? two_eps_q[q] : two_eps);
+        const float bq = bmeta ? two_eps_q[512 + q] : 0.0f;
+        finalize_body<DT, NITER, 1>(rows_, dpad, qn + (int64_t)q * dpad, hits + (int64_t)q * cap_q, total, part, nparts, k, eps1, bq, bmeta, row_base,
+                                    out_keys ? out_keys + (int64_t)q * k : nullptr, out_dist ? out_dist + (int64_t)q * k : nullptr,
+                                    out_rows ? out_rows + (int64_t)q * k : nullptr, part_keys ? part_keys + ((int64_t)q * nparts + part) * k : nullptr, stats);
+        return;
+    }
+    if (blockIdx.y != 0) return;
+    // the queue: queries with a truncated list, in query order (every scan workgroup computes the same list)
+    __shared__ unsigned s_fb[kTileQ];
+    __shared__ unsigned s_cnt[kWavesHere + 1];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool over = tid < nq && hit_cnt[tid * kHitCntStride] > (unsigned)cap_q;   // (nq <= 256 < kFinThreads)
+    const u64 mask = __ballot(over);
+    if (lane == 0) s_cnt[wave] = (unsigned)__popcll(mask);
+    __syncthreads();
+    unsigned base = 0, total = 0;
+    for (int w = 0; w < kWavesHere; ++w) {
+        if (w < wave) base += s_cnt[w];
+        total += s_cnt[w];
+    }
+    if (total == 0) return;   // (uniform: nothing was truncated — the normal case)
+    if (over) s_fb[base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = (unsigned)tid;
+    __syncthreads();
+    // (4 queries per pass over the rows, not 8: the role is rare, and its query registers must not push the finalize role into scratch)
+    scan_topk_body<DT, 4, NITER, 1, kWavesHere>(rows_, n, dpad, qn, (int)total, k, row_base, fb_partial, fb_stride_q, s_fb, true, fb_done, out_keys, out_dist, out_rows,
+                                                 stats ? stats + 2 : nullptr, (int)blockIdx.x - nq, (int)gridDim.x - nq, reinterpret_cast<u64*>(smem_raw));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -434,10 +503,11 @@ __device__ __forceinline__ uint32_t quantize4(const float (&v)[4], float inv_sca
 template <int DT>
 __global__ __launch_bounds__(256) void shadow8_from_rows_kernel(const void* __restrict__ rows_, int64_t first32, int64_t n, int dpad, int dpad8,
                                                                 uint4* __restrict__ shadow8, float* __restrict__ rscale,
-                                                                unsigned* __restrict__ eps_r_bits) {
+                                                                float2* __restrict__ bmeta) {
     constexpr int kRowDwords = 516;  // 512 + 4: sixteen rows read column-wise hit 64 different banks
     __shared__ __attribute__((aligned(16))) uint32_t tile[16 * kRowDwords];
     __shared__ float s_max[4];
+    __shared__ float s_err[4];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
     const int64_t row32 = first32 + (int64_t)blockIdx.x * 32;
     const int nch = dpad >> 2, nch8 = dpad8 >> 2, nsteps8 = dpad8 >> 7;
@@ -507,11 +577,38 @@ __global__ __launch_bounds__(256) void shadow8_from_rows_kernel(const void* __re
         }
         __syncthreads();
     }
-    // one device-scope atomic per wave at most, and only when it would raise the maximum (a single address hit by
-    // one atomic per row made this kernel 10x slower than its bytes); non-negative floats order as their bits
-    if (lane == 0) {
-        const unsigned bits = __float_as_uint(wave_err);
-        if (bits > *reinterpret_cast<volatile unsigned*>(eps_r_bits)) atomicMax(eps_r_bits, bits);
+    // The block's meta data: its scale and the largest quantisation error norm |c - c~| among its rows.  The filter's bound is
+    // evaluated PER BLOCK with this norm (round 2 folded every row's norm into one device-wide maximum that could only grow: one
+    // badly quantising row widened every query's slack for the life of the index); the device-wide maximum that the
+    // first-generation kernels and the host's "is int8 usable at all" test still use is re-derived from these after every
+    // build (eps_max_kernel), so it follows the rows that are stored NOW.
+    if (lane == 0) s_err[wave] = wave_err;
+    __syncthreads();
+    if (threadIdx.x == 0 && row32 < n) bmeta[row32 >> 5] = make_float2(scale, fmaxf(fmaxf(s_err[0], s_err[1]), fmaxf(s_err[2], s_err[3])));
+}
+
+// eps_max_kernel: *eps_r_bits = the largest block error norm over blocks [0, nblocks) (one workgroup; after every shadow build)
+// eps_r_bits[1] = how many blocks lie above `wide` (the host's "int8 bound useless" level): the per-block kernels only pay for those blocks
+__global__ __launch_bounds__(1024) void eps_max_kernel(const float2* __restrict__ bmeta, int64_t nblocks, unsigned* __restrict__ eps_r_bits, float wide) {
+    __shared__ float s_part[16];
+    __shared__ unsigned s_wide;
+    if (threadIdx.x == 0) s_wide = 0u;
+    __syncthreads();
+    float m = 0.0f;
+    unsigned nw = 0;
+    for (int64_t i = threadIdx.x; i < nblocks; i += 1024) {
+        const float e = bmeta[i].y;
+        m = fmaxf(m, e);
+        nw += e > wide ? 1u : 0u;
+    }
+    m = butterfly_max(m);
+    if (nw) atomicAdd(&s_wide, nw);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) m = fmaxf(m, s_part[w]);
+        eps_r_bits[0] = __float_as_uint(m);
+        eps_r_bits[1] = s_wide;
     }
 }
 
@@ -529,7 +626,7 @@ __global__ __launch_bounds__(256) void prep_queries8_kernel(const float* __restr
     const int nch = dpad >> 2, nch8 = dpad8 >> 2;
     if (q >= B) {
         for (int j = lane; j < nch8; j += kWave) qfrag8[codd::qfrag_piece_index(q, j >> 2) * 4 + (j & 3)] = 0u;
-        if (lane == 0) { qmeta[q] = 0.0f; qmeta[256 + q] = 0.0f; }
+        if (lane == 0) { qmeta[q] = 0.0f; qmeta[256 + q] = 0.0f; qmeta[512 + q] = 0.0f; qmeta[768 + q] = 0.0f; }
         return;
     }
     const float* x = in + (int64_t)q * d;
@@ -567,7 +664,168 @@ __global__ __launch_bounds__(256) void prep_queries8_kernel(const float* __restr
         const float eq = __builtin_sqrtf(err2) * 1.0001f + 1e-7f, er = __uint_as_float(*eps_r_bits);
         qmeta[q] = scale;
         qmeta[256 + q] = slack_scale * 2.0f * (eq * (1.01f + er) + 1.001f * er + 2e-6f);
+        // the same bound split by what it depends on: eps(q, block) = A(q) + B(q) * e_block, e_block = the block's own error norm
+        // (bmeta[].y) in place of the device-wide maximum er — what i8_tile_kernel and finalize evaluate per 32-row block
+        qmeta[512 + q] = slack_scale * (eq * 1.01f + 2e-6f);
+        qmeta[768 + q] = slack_scale * (eq + 1.001f);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// small_batch_kernel<DT, NITER, NS>: ONE query answered in ONE launch (BASELINE configs[1]: 1M x 768, B = 1).  The filter chain
+// of a batch is six dependent launches (query preparation, sample, thresholds, filter, finalize, merge); at B = 1 over 1M rows
+// they cost as much again as streaming the int8 shadow once.  Here:
+//   every workgroup : wave 0 quantises the query (same arithmetic as prep_queries8_kernel) into LDS while the other waves' first
+//     loads are already in flight; then every wave streams its share of the int8 shadow — 16 rows x dpad8 bytes at a time
+//     (2 NS contiguous 1-KiB chunks of the fragment order, the next unit's loads issued before this unit's arithmetic);
+//     lane (kq, r) holds 16 elements of row r: v_dot4 against the query's 16 bytes from LDS, two cross-lane adds — keeps
+//     its best 64 approximate scores (WaveTopK) and publishes the best kSbKeep of them plus `dropmax`, the best key it did NOT
+//     publish (0: none);
+//   the workgroup that finishes LAST (device-scope fence + arrival ticket) : finalize_body over the published candidates — the
+//     k best approximate ones re-scored exactly give L' <= s_k, every row whose approximate score is >= L' - eps(q) is
+//     re-scored exactly (canonical fp32 expression), top-k written.  MARGIN TEST: if some wave's dropmax is >= L' - eps(q) a
+//     candidate may have been dropped: the query goes to the exact-scan fallback queue (the list-driven scan launch behind
+//     this kernel: normally empty).  No thresholds, no sample pass: the bound is the same eps(q) = |q - q~| (1.01 + eps_r) +
+//     1.001 eps_r + 2e-6 as the int8 filter's (device-wide eps_r).
+// Results are bit-identical to every other path: the survivors' scores are the canonical ones.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kSbKeep = 8;        // keys a wave publishes
+constexpr int kSbThreads = kFinThreads;
+static_assert(kSbThreads == 512, "finalize_body's workgroup");
+template <int DT, int NITER, int NS>
+__global__ __launch_bounds__(kSbThreads) void small_batch_kernel(const uint4* __restrict__ shadow8, const float2* __restrict__ bmeta, const void* __restrict__ rows_,
+                                                                  int64_t n, int d, int dpad, const float* __restrict__ in, int k, uint32_t row_base,
+                                                                  const unsigned* __restrict__ eps_r_bits, float* __restrict__ qn, u64* __restrict__ cand,
+                                                                  u64* __restrict__ dropmax, unsigned* __restrict__ ticket, unsigned* __restrict__ fb_count,
+                                                                  unsigned* __restrict__ fb_list, u64* __restrict__ out_keys, float* __restrict__ out_dist,
+                                                                  int64_t* __restrict__ out_rows, unsigned long long* __restrict__ stats) {
+    constexpr int kWaves = kSbThreads / kWave;
+    constexpr int kDpad8 = NS * 128;
+    typedef unsigned sb_u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) unsigned char s_q8[kDpad8];   // the query's int8 bytes, natural order
+    __shared__ float s_qscale, s_eps, s_lo;
+    __shared__ unsigned s_last;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nch = dpad >> 2;
+    const int64_t G = gridDim.x;
+    const int64_t nunits = (n + 15) >> 4;
+    const int64_t W = G * kWaves;
+    const int64_t wave_global = (int64_t)blockIdx.x * kWaves + wave;
+
+    // the chunks of unit u (16 rows): read-once stream, non-temporal.  A unit index past the end is clamped (the loads are
+    // unconditional: a conditional load makes hipcc drain the queue at every join); its results are never offered.
+    auto load_unit = [&](sb_u32x4(&c)[2 * NS], float& scale, int64_t u) __attribute__((always_inline)) {
+        const int64_t uu = u < nunits ? u : nunits - 1;
+        scale = bmeta[uu >> 1].x;   // (in front of the chunks: the queue retires in order, a load issued behind them would drain the prefetch)
+        const uint4* src = shadow8 + ((uu >> 1) * NS * 4 + (uu & 1) * 2) * 64 + lane;   // chunk (s, ks) at + (s * 4 + ks) * 64 pieces
+#pragma unroll
+        for (int j = 0; j < 2 * NS; ++j) c[j] = __builtin_nontemporal_load(reinterpret_cast<const sb_u32x4*>(src + ((j >> 1) * 4 + (j & 1)) * 64));
+    };
+    sb_u32x4 ca[2 * NS], cb[2 * NS];
+    float sa = 0.0f, sb = 0.0f;
+    int64_t u = wave_global;
+    load_unit(ca, sa, u);
+
+    // ---- the query: normalise (block 0 also stores qn: the last workgroup and the fallback scan read it) and quantise ----
+    if (wave == 0) {
+        const float nrm = canonical_norm(in, d, nch, lane);
+        const bool zero_row = !(nrm > 0.0f) || !(nrm < INFINITY);
+        float vmax = 0.0f;
+        for (int j = lane; j < nch; j += kWave) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = j * 4 + e;
+                const float t = i < d ? in[i] : 0.0f;
+                v[e] = zero_row ? 0.0f : t / nrm;
+                vmax = fmaxf(vmax, fabsf(v[e]));
+            }
+            if (blockIdx.x == 0) reinterpret_cast<float4*>(qn)[j] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        vmax = butterfly_max(vmax);
+        const float scale = vmax > 0.0f ? vmax / 127.0f : 0.0f, inv_scale = vmax > 0.0f ? 127.0f / vmax : 0.0f;
+        float err2 = 0.0f;
+        for (int j = lane; j < kDpad8 / 4; j += kWave) {
+            float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (j < nch) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = j * 4 + e;
+                    const float t = i < d ? in[i] : 0.0f;
+                    v[e] = zero_row ? 0.0f : t / nrm;
+                }
+            }
+            reinterpret_cast<uint32_t*>(s_q8)[j] = quantize4(v, inv_scale, scale, err2);
+        }
+        err2 = butterfly_sum(err2);
+        if (lane == 0) {
+            const float eq = __builtin_sqrtf(err2) * 1.0001f + 1e-7f, er = __uint_as_float(*eps_r_bits);
+            s_qscale = scale;
+            s_eps = eq * (1.01f + er) + 1.001f * er + 2e-6f;
+        }
+    }
+    __syncthreads();
+    const float qscale = s_qscale;
+
+    // ---- the stream ----
+    WaveTopK<1> L;
+    L.init();
+    const int kq = lane >> 4, r = lane & 15;
+    auto score_unit = [&](const sb_u32x4(&c)[2 * NS], float scale, int64_t uu) __attribute__((always_inline)) {
+        int acc = 0;
+#pragma unroll
+        for (int j = 0; j < 2 * NS; ++j) {
+            const uint4 b = *reinterpret_cast<const uint4*>(s_q8 + j * 64 + kq * 16);
+            acc = __builtin_amdgcn_sdot4((int)c[j][0], (int)b.x, acc, false);
+            acc = __builtin_amdgcn_sdot4((int)c[j][1], (int)b.y, acc, false);
+            acc = __builtin_amdgcn_sdot4((int)c[j][2], (int)b.z, acc, false);
+            acc = __builtin_amdgcn_sdot4((int)c[j][3], (int)b.w, acc, false);
+        }
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+        const int64_t block = uu >> 1;
+        const int64_t row = (block << 5) + 16 * (uu & 1) + r;
+        const float score = (float)acc * scale * qscale;
+        const u64 key = (lane < 16 && row < n) ? make_key(score, (uint32_t)row) : 0ull;
+        L.offer_lanes(key, kWave, lane);
+    };
+    while (u < nunits) {
+        load_unit(cb, sb, u + W);
+        score_unit(ca, sa, u);
+        u += W;
+        if (u >= nunits) break;
+        load_unit(ca, sa, u + W);
+        score_unit(cb, sb, u);
+        u += W;
+    }
+
+    // ---- publish: the wave's best kSbKeep keys and the best key it keeps to itself ----
+    if (lane < kSbKeep) cand[wave_global * kSbKeep + lane] = L.v[0];
+    const u64 dropped = readlane_u64(L.v[0], kSbKeep);
+    if (lane == 0) dropmax[wave_global] = dropped;
+
+    // ---- the last workgroup to arrive answers the query ----
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(ticket, 1u) == (unsigned)(G - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (tid == 0) {
+        *ticket = 0u;    // (the next search finds the ticket at zero: no clearing launch)
+        *fb_count = 0u;  // (the fallback queue of THIS search starts empty; the scan behind this kernel reads it)
+    }
+    __syncthreads();
+    finalize_body<DT, NITER, 1>(rows_, dpad, qn, cand, (unsigned)(W * kSbKeep), 0u, 1u, k, s_eps, 0.0f, nullptr, row_base, out_keys, out_dist, out_rows, nullptr, stats,
+                                &s_lo);
+    // margin test: could a wave have kept a row to itself that belongs among the survivors?
+    const float lo = s_lo;
+    unsigned bad = 0;
+    for (int64_t i = tid; i < W; i += kSbThreads) {
+        const u64 dm = dropmax[i];
+        if (dm && key_score(dm) >= lo) bad = 1u;
+    }
+    if (__syncthreads_or((int)bad) && tid == 0) fb_list[atomicAdd(fb_count, 1u)] = 0u;
 }
 
 // row_norm_check_kernel: largest | |c| - 1 | over stored rows [first, first + n) that are not all-zero, folded into *dev_bits
@@ -712,7 +970,8 @@ struct FilterCtl {
     unsigned flags[FLAG_WORDS];
     unsigned fb_count;         // queries queued for the exact-scan fallback ...
     unsigned fb_done;          // ... blocks of the fallback scan that have finished (the last one merges)
-    unsigned pad_[2];
+    unsigned sb_ticket;        // small_batch_kernel's arrival counter (its last workgroup puts it back to zero)
+    unsigned pad_[1];
     unsigned fb_list[kTileQ];  // ... and which ones
 };
 
@@ -726,13 +985,14 @@ struct WorkBufs {
     u64* partial = nullptr;    int64_t partial_cap = 0;   // [B][blocks][k]
     u64* keys_tmp = nullptr;   int64_t keys_tmp_cap = 0;  // [B][k]
     uint4* qfrag = nullptr;    int64_t qfrag_cap = 0;     // pieces
-    float* thr = nullptr;                                  // [256]
+    float* thr = nullptr;                                  // [512]: thr[256], thr0[256]
     u64* bucket_max = nullptr; int64_t bucket_cap = 0;     // [256][sample tiles] best (score, row) key per sampled tile
     u64* hits = nullptr;       int64_t hits_cap = 0;      // [256][hit_cap_q]
     FilterCtl* ctl = nullptr;                              // device
     u64* fb_partial = nullptr; int64_t fb_partial_cap = 0; // [256][blocks][k] partials of the fallback scan
     uint4* qfrag8 = nullptr;   int64_t qfrag8_cap = 0;    // int8 query fragments (pieces)
-    float* qmeta = nullptr;                                // [512]: query scales, 2*eps per query (int8 filter)
+    float* qmeta = nullptr;                                // [1024]: per query: scale, 2*eps (device-wide bound), A, B (eps per block = A + B e_block)
+    u64* sb_cand = nullptr;    int64_t sb_cand_cap = 0;    // small_batch_kernel: [waves][kSbKeep] published keys, then [waves] dropmax
     u64* probe_keys = nullptr; int64_t probe_cap = 0;      // IVF: [B][nprobe] coarse keys
     u64* ivf_partial = nullptr; int64_t ivf_partial_cap = 0;
 };
@@ -801,11 +1061,18 @@ struct codd_knn_index : WorkBufs {
     int i8v2 = 2;                 // batches of 65..256 queries on rows of >= 384 elements (3 K-steps) take i8_tile_kernel (filter_i8.h); 1: only rows of
                                   // more than 512 elements (below, the first-generation kernel keeps the query block resident in LDS: 6-12 % slower); 0: never
     int i8v2_half = 1;            // ... and so do batches of 65..128 queries (its 8-query-block instantiation)
-    int sample_div8 = 20;         // its thresholds come from a larger sample (the int8 slack is ~5x the bf16 one)
+    int fuse_fallback = 1;        // batches above 64 queries, k <= 64: finalize and the exact-scan fallback in one launch ("fuse_fallback": 0 = two launches)
+    int small_batch_max = 0;      // 1: a single query is answered in one launch by small_batch_kernel where it applies.  OFF by default: measured SLOWER than the
+                                  // six-launch chain (1M x 768, B = 1: kernel 0.27 ms, p50 0.33 ms against 0.25 ms; profiles/r3/small_batch_latency.txt)
+    int64_t stat_small_batch = 0;
+    int per_block = 7;            // the int8 bound per 32-row block: bit 0 in i8_tile_kernel, bit 1 in finalize ("per_block" option; 0 = the device-wide bound everywhere)
+    int i8_pair = 1;              // rows of 6, 12, ... K-steps: the staged tile program with one workgroup barrier per two K-steps ("i8_pair" option: 0 = one per K-step)
+    int sample_div8 = 28;         // its thresholds come from a larger sample (the int8 slack is ~5x the bf16 one)
     int sample_rounds8 = 3;       // ... of at least this many rounds of workgroups (one tile each) when the batch has more than 32 queries
     uint4* shadow8 = nullptr;
     int64_t shadow8_rows = 0;     // rows the allocation covers (multiple of 256)
     float* rscale = nullptr;      // [shadow8_rows]
+    float2* bmeta = nullptr;      // [shadow8_rows / 32]: per 32-row block {scale, largest error norm |c - c~| of its rows}; NaN scale: no row of the block exists
     unsigned* eps_r_bits = nullptr;  // device scalar: max row error norm (float bits)
     int64_t shadow8_epoch = -1;
     int64_t dirty_lo = 0, dirty_hi = 0;  // rows written since the int8 shadow was last brought up to date: [lo, hi)
@@ -818,6 +1085,7 @@ struct codd_knn_index : WorkBufs {
     float* eps_r_host = nullptr;        // pinned
     hipEvent_t eps_r_copied = nullptr;
     float eps_r_known = 0.0f;
+    int64_t wide_blocks_known = 0;      // blocks whose error norm exceeds shadow8_max_eps, as last read back
     float shadow8_max_eps = 0.04f;
     // Which filter suits the DATA is watched too: on corpora with dense clusters the wider int8 slack lets thousands of
     // rows per query through to the exact re-scoring, where the bf16 filter (a fifth of the slack) is the faster one
@@ -835,6 +1103,7 @@ struct codd_knn_index : WorkBufs {
     int shadow8_cooldown = 256;
     int cooldown_left = 0;
     int64_t stat_cooldowns = 0;
+    double cooldown_surv8 = 0.0;          // survivors per query of the int8 passes that started the current cooldown
     int64_t cooldown_useless_epoch = -1;  // row epoch at which the bf16 filter was seen to leave as many survivors as the int8 one: no more cooldowns until rows change
     float exp_slack_scale = 1.0f;  // always 1 in the shipped library; "exp_slack_pct" exists only in -DCODD_EXPERIMENTS=1 builds
 
@@ -1171,12 +1440,13 @@ template <int DT, int NITER>
 void launch_finalize_slots(int slots, int B, hipStream_t st, const codd_knn_index* ix, const float* qn, int k, float two_eps,
                            uint32_t row_base, u64* out_keys, const float* two_eps_q, int nparts, u64* part_keys, float* out_dist, int64_t* out_rows) {
     FilterCtl* c = ix->ctl;
+    const float2* bm = two_eps_q && (ix->per_block & 2) ? ix->bmeta : nullptr;  // (the int8 passes: slack per 32-row block)
     if (slots == 1)
         hipLaunchKernelGGL((finalize_kernel<DT, NITER, 1>), dim3(B, nparts), dim3(kFinThreads), 0, st, ix->rows, ix->dpad, qn, ix->hits, c->hit_cnt,
-                           ix->hit_cap_q, c->flags, k, two_eps, row_base, out_keys, &c->fb_count, c->fb_list, ix->dstats, two_eps_q, part_keys, out_dist, out_rows);
+                           ix->hit_cap_q, c->flags, k, two_eps, row_base, out_keys, &c->fb_count, c->fb_list, ix->dstats, two_eps_q, part_keys, out_dist, out_rows, bm);
     else
         hipLaunchKernelGGL((finalize_kernel<DT, NITER, 2>), dim3(B, nparts), dim3(kFinThreads), 0, st, ix->rows, ix->dpad, qn, ix->hits, c->hit_cnt,
-                           ix->hit_cap_q, c->flags, k, two_eps, row_base, out_keys, &c->fb_count, c->fb_list, ix->dstats, two_eps_q, part_keys, out_dist, out_rows);
+                           ix->hit_cap_q, c->flags, k, two_eps, row_base, out_keys, &c->fb_count, c->fb_list, ix->dstats, two_eps_q, part_keys, out_dist, out_rows, bm);
 }
 
 template <int DT>
@@ -1203,8 +1473,11 @@ int ensure_filter_workspace(codd_knn_index* ix) {
     if ((rc = ensure_buf(&ix->qfrag, &ix->qfrag_cap, (int64_t)kTileQ * (ix->dpad / 8))) != 0) return rc;
     if ((rc = ensure_buf(&ix->bucket_max, &ix->bucket_cap, (int64_t)ix->sample_tiles * kTileQ)) != 0) return rc;
     if ((rc = ensure_buf(&ix->hits, &ix->hits_cap, (int64_t)kTileQ * ix->hit_cap_q)) != 0) return rc;
-    if (!ix->thr) HIP_TRY(hipMalloc((void**)&ix->thr, kTileQ * sizeof(float)));
-    if (!ix->ctl) HIP_TRY(hipMalloc((void**)&ix->ctl, sizeof(FilterCtl)));
+    if (!ix->thr) HIP_TRY(hipMalloc((void**)&ix->thr, 2 * kTileQ * sizeof(float)));  // thr[q], then thr0[q] (per-block form, int8 tile kernel)
+    if (!ix->ctl) {
+        HIP_TRY(hipMalloc((void**)&ix->ctl, sizeof(FilterCtl)));
+        HIP_TRY(hipMemset(ix->ctl, 0, sizeof(FilterCtl)));  // (the filter passes clear it per pass; small_batch_kernel relies on zeros left behind)
+    }
     if (!ix->dstats) {
         HIP_TRY(hipMalloc((void**)&ix->dstats, 4 * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(ix->dstats, 0, 4 * sizeof(unsigned long long)));
@@ -1219,17 +1492,14 @@ int ensure_filter_workspace(codd_knn_index* ix) {
             (const void*)&gemm_filter_kernel<MODE_DUMP, 8>};
         for (const void* fn : fns)
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter_lds_bytes(MODE_FILTER)));
-        HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_FILTER, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_FILTER)));
-        HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_FILTER, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_FILTER)));
-        HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_SAMPLE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_SAMPLE)));
-        HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_FILTER, true, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_FILTER)));
-        HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_FILTER, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_FILTER)));
-        HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_SAMPLE, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_SAMPLE)));
-        const void* res_fns[] = {(const void*)&i8_tile_kernel<MODE_FILTER, true, 16, true>, (const void*)&i8_tile_kernel<MODE_FILTER, false, 16, true>,
-                                 (const void*)&i8_tile_kernel<MODE_FILTER, true, 8, true>, (const void*)&i8_tile_kernel<MODE_FILTER, false, 8, true>};
-        for (const void* fn : res_fns) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_FILTER)));
-        HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_SAMPLE, false, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_SAMPLE)));
-        HIP_TRY(hipFuncSetAttribute((const void*)&i8_tile_kernel<MODE_SAMPLE, false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_SAMPLE)));
+        const void* tile_fns[] = {(const void*)&i8_tile_kernel<MODE_FILTER, 0>, (const void*)&i8_tile_kernel<MODE_FILTER, 1>, (const void*)&i8_tile_kernel<MODE_FILTER, 2>,
+                                  (const void*)&i8_tile_kernel<MODE_FILTER, 0, 8>, (const void*)&i8_tile_kernel<MODE_FILTER, 1, 8>, (const void*)&i8_tile_kernel<MODE_FILTER, 2, 8>,
+                                  (const void*)&i8_tile_kernel<MODE_FILTER, 1, 16, true>, (const void*)&i8_tile_kernel<MODE_FILTER, 0, 16, true>,
+                                  (const void*)&i8_tile_kernel<MODE_FILTER, 1, 8, true>, (const void*)&i8_tile_kernel<MODE_FILTER, 0, 8, true>};
+        for (const void* fn : tile_fns) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_FILTER)));
+        const void* tile_sample_fns[] = {(const void*)&i8_tile_kernel<MODE_SAMPLE, 0>, (const void*)&i8_tile_kernel<MODE_SAMPLE, 0, 8>,
+                                         (const void*)&i8_tile_kernel<MODE_SAMPLE, 0, 16, true>, (const void*)&i8_tile_kernel<MODE_SAMPLE, 0, 8, true>};
+        for (const void* fn : tile_sample_fns) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_SAMPLE)));
         attr_set.store(true, std::memory_order_release);
     }
     return CODD_KNN_OK;
@@ -1346,8 +1616,8 @@ int ensure_shadow8(codd_knn_index* ix, hipStream_t st) {
     const int64_t need = (n + kTileRows - 1) / kTileRows * kTileRows;
     int64_t first = ix->dirty_lo, m = ix->dirty_hi - ix->dirty_lo;  // rows to (re)quantise
     if (!ix->eps_r_bits) {
-        HIP_TRY(hipMalloc((void**)&ix->eps_r_bits, sizeof(unsigned)));
-        HIP_TRY(hipMemsetAsync(ix->eps_r_bits, 0, sizeof(unsigned), st));
+        HIP_TRY(hipMalloc((void**)&ix->eps_r_bits, 2 * sizeof(unsigned)));
+        HIP_TRY(hipMemsetAsync(ix->eps_r_bits, 0, 2 * sizeof(unsigned), st));
     }
     if (need > ix->shadow8_rows) {
         // (every stream that may still read the old allocation has to be done with it)
@@ -1355,32 +1625,37 @@ int ensure_shadow8(codd_knn_index* ix, hipStream_t st) {
         if ((rcw = wait_searching_streams(ix)) != 0) return rcw;
         if (ix->shadow8) (void)hipFree(ix->shadow8);
         if (ix->rscale) (void)hipFree(ix->rscale);
-        ix->shadow8 = nullptr; ix->rscale = nullptr; ix->shadow8_rows = 0;
+        if (ix->bmeta) (void)hipFree(ix->bmeta);
+        ix->shadow8 = nullptr; ix->rscale = nullptr; ix->bmeta = nullptr; ix->shadow8_rows = 0;
         const int64_t rows = need + need / 8;  // head room: appends do not reallocate every time
         const int64_t rows_al = (rows + kTileRows - 1) / kTileRows * kTileRows;
         HIP_TRY(hipMalloc((void**)&ix->shadow8, (size_t)rows_al * dpad8));
         HIP_TRY(hipMalloc((void**)&ix->rscale, (size_t)rows_al * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&ix->bmeta, (size_t)(rows_al / 32 + 64) * sizeof(float2)));  // (+64: a wave's DMA reads 32 blocks from a tile's first one)
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ix->bmeta, (int)0x7fc00000, (size_t)(rows_al / 32 + 64) * 2, st));  // NaN: no such block yet
         ix->shadow8_rows = rows_al;
         // rows beyond the count are masked (row < n), their bytes only have to be defined
         HIP_TRY(hipMemsetAsync(ix->shadow8, 0, (size_t)rows_al * dpad8, st));
-        HIP_TRY(hipMemsetAsync(ix->eps_r_bits, 0, sizeof(unsigned), st));
+        HIP_TRY(hipMemsetAsync(ix->eps_r_bits, 0, 2 * sizeof(unsigned), st));
         first = 0; m = n;  // a fresh allocation holds nothing yet
     }
     if (!ix->shadow8_ready) HIP_TRY(hipEventCreateWithFlags(&ix->shadow8_ready, hipEventDisableTiming));
     if (m > 0) {
-        // an update only ever raises *eps_r (the bound stays valid for rows that have been overwritten since).
         // Whole 32-row blocks (one scale per block): the rows that share a block with the dirty range are quantised again,
-        // with the block's new scale.
+        // with the block's new scale, and the block's error norm is measured again.
         const int64_t last = first + m;
         first = first / 32 * 32;
         m = (last + 31) / 32 * 32 - first;
         const dim3 grid((unsigned)(m / 32)), block(256);
         uint4* s8 = ix->shadow8;
         switch (ix->dtype) {
-            case DT_F32: hipLaunchKernelGGL(shadow8_from_rows_kernel<DT_F32>, grid, block, 0, st, ix->rows, first, n, ix->dpad, dpad8, s8, ix->rscale, ix->eps_r_bits); break;
-            case DT_BF16: hipLaunchKernelGGL(shadow8_from_rows_kernel<DT_BF16>, grid, block, 0, st, ix->rows, first, n, ix->dpad, dpad8, s8, ix->rscale, ix->eps_r_bits); break;
-            default: hipLaunchKernelGGL(shadow8_from_rows_kernel<DT_F16>, grid, block, 0, st, ix->rows, first, n, ix->dpad, dpad8, s8, ix->rscale, ix->eps_r_bits); break;
+            case DT_F32: hipLaunchKernelGGL(shadow8_from_rows_kernel<DT_F32>, grid, block, 0, st, ix->rows, first, n, ix->dpad, dpad8, s8, ix->rscale, ix->bmeta); break;
+            case DT_BF16: hipLaunchKernelGGL(shadow8_from_rows_kernel<DT_BF16>, grid, block, 0, st, ix->rows, first, n, ix->dpad, dpad8, s8, ix->rscale, ix->bmeta); break;
+            default: hipLaunchKernelGGL(shadow8_from_rows_kernel<DT_F16>, grid, block, 0, st, ix->rows, first, n, ix->dpad, dpad8, s8, ix->rscale, ix->bmeta); break;
         }
+        HIP_TRY(hipGetLastError());
+        // the device-wide maximum of the block error norms, over the rows stored now (not a running maximum)
+        hipLaunchKernelGGL(eps_max_kernel, dim3(1), dim3(1024), 0, st, ix->bmeta, (n + 31) / 32, ix->eps_r_bits, ix->shadow8_max_eps);
         HIP_TRY(hipGetLastError());
     }
     {
@@ -1391,11 +1666,12 @@ int ensure_shadow8(codd_knn_index* ix, hipStream_t st) {
     }
     HIP_TRY(hipEventRecord(ix->shadow8_ready, st));
     if (!ix->eps_r_host) {
-        HIP_TRY(hipHostMalloc((void**)&ix->eps_r_host, sizeof(float), hipHostMallocDefault));
-        *ix->eps_r_host = 0.0f;
+        HIP_TRY(hipHostMalloc((void**)&ix->eps_r_host, 2 * sizeof(float), hipHostMallocDefault));
+        ix->eps_r_host[0] = 0.0f;
+        ix->eps_r_host[1] = 0.0f;
         HIP_TRY(hipEventCreateWithFlags(&ix->eps_r_copied, hipEventDisableTiming));
     }
-    HIP_TRY(hipMemcpyAsync(ix->eps_r_host, ix->eps_r_bits, sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(ix->eps_r_host, ix->eps_r_bits, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipEventRecord(ix->eps_r_copied, st));
     ix->shadow8_stream = st;
     ix->shadow8_epoch = ix->epoch;
@@ -1456,7 +1732,7 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
         if (tile_v2) {
             // (the sample pass keeps the generic program: its tile-structured instantiation spills inside the loop)
 #define CODD_LAUNCH_TILE8_SAMPLE(NQB, RES)                                                                                                    \
-    hipLaunchKernelGGL((i8_tile_kernel<MODE_SAMPLE, false, NQB, RES>), g, b, i8_lds_bytes(MODE_SAMPLE), st, shadow, qfrag, n, nsteps, ts, stride, \
+    hipLaunchKernelGGL((i8_tile_kernel<MODE_SAMPLE, 0, NQB, RES>), g, b, i8_lds_bytes(MODE_SAMPLE), st, shadow, qfrag, n, nsteps, ts, stride, \
                        nullptr, ix->bucket_max, nullptr, nullptr, 0, nullptr, ix->rscale, ix->qmeta)
             const bool res = i8_tile_resident(nsteps, nbq) && ix->resident_q;  // the query block fits the four LDS slices: loaded once per workgroup
             if (nbq == 8) {
@@ -1502,7 +1778,7 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
         const int niter_t = (nch_t + kWave - 1) / kWave;
 #define CODD_ANCHOR(DT, NI, SL)                                                                                                       \
     hipLaunchKernelGGL((anchor_thr_kernel<DT, NI, SL>), dim3(kTileQ), dim3(kAnchorWaves * kWave), 0, st, ix->bucket_max, ts, nq, k, ix->rows, ix->dpad, qn, \
-                       eps, slack_q, ix->thr)
+                       eps, slack_q, ix->thr, use8 ? ix->thr + kTileQ : nullptr)
 #define CODD_ANCHOR_NI(DT, SL)                                \
     switch (niter_t) {                                         \
         case 1: CODD_ANCHOR(DT, 1, SL); break;                 \
@@ -1534,16 +1810,27 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     hipLaunchKernelGGL((gemm_filter_kernel<MODE_FILTER, NBQ, 1, 2>), g, b, lds, st, shadow, qfrag, n, nsteps, ntiles, \
                        (int64_t)1, ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, nullptr, ix->rscale, ix->qmeta)
         if (tile_v2) {
+#ifdef CODD_I8_EXP_STAMPS  // (diagnostic build: the filter pass writes its per-wave phase stamps over the sample's bucket keys, which anchor_thr has consumed)
+#define CODD_STAMP_BUF ix->bucket_max
+#else
+#define CODD_STAMP_BUF nullptr
+#endif
 #define CODD_LAUNCH_TILE8(S3, NQB, RES)                                                                                                              \
     hipLaunchKernelGGL((i8_tile_kernel<MODE_FILTER, S3, NQB, RES>), g, b, i8_lds_bytes(MODE_FILTER), st, shadow, qfrag, n, nsteps, ntiles, (int64_t)1, \
-                       ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, ix->rscale, ix->qmeta)
+                       (ix->per_block & 1) ? ix->thr + kTileQ : ix->thr, CODD_STAMP_BUF, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, ix->rscale, ix->qmeta, \
+                       (ix->per_block & 4) ? ix->bmeta : nullptr, (ix->per_block & 1) ? 1.0f : 0.0f)
             const bool res = i8_tile_resident(nsteps, nbq) && ix->resident_q;
+            // tile structure: rows of 6, 12, ... K-steps (768 elements: the headline shape) run the staged program with one barrier
+            // per TWO K-steps; other multiples of 3 one per K-step; the rest the generic interval loop
+            const bool pair = nsteps % 6 == 0 && ix->i8_pair;
             if (nbq == 8) {
-                if (res) { if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(true, 16, true); else CODD_LAUNCH_TILE8(false, 16, true); }
-                else { if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(true, 16, false); else CODD_LAUNCH_TILE8(false, 16, false); }
+                if (res) { if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(1, 16, true); else CODD_LAUNCH_TILE8(0, 16, true); }
+                else if (pair) CODD_LAUNCH_TILE8(2, 16, false);
+                else { if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(1, 16, false); else CODD_LAUNCH_TILE8(0, 16, false); }
             } else {
-                if (res) { if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(true, 8, true); else CODD_LAUNCH_TILE8(false, 8, true); }
-                else { if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(true, 8, false); else CODD_LAUNCH_TILE8(false, 8, false); }
+                if (res) { if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(1, 8, true); else CODD_LAUNCH_TILE8(0, 8, true); }
+                else if (pair) CODD_LAUNCH_TILE8(2, 8, false);
+                else { if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(1, 8, false); else CODD_LAUNCH_TILE8(0, 8, false); }
             }
 #undef CODD_LAUNCH_TILE8
         } else if (use8 && partial6) {
@@ -1581,6 +1868,39 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     // query's re-scoring out between several workgroups, then merge their lists
     const int nparts = use8 ? (nq <= 8 ? 16 : (nq <= 32 ? 8 : (nq <= 64 ? 4 : 1))) : 1;
     if (nparts > 1 && (rc = ensure_buf(&ix->partial, &ix->partial_cap, (int64_t)nq * nparts * k)) != 0) return rc;
+    // one list slot per lane and one workgroup per query (the large batches): finalize and the exact-scan fallback share ONE
+    // launch — the scan workgroups derive the queue from the hit counters and leave at once when it is empty
+    if (slots == 1 && nparts == 1 && ix->fuse_fallback && !(ix->dtype != DT_F32 && niter == 4)) {  // (2-byte rows above 1536 elements: the fused kernel spills)
+        int nit;
+        int64_t blocks;
+        if ((rc = scan_geometry(ix, n, &nit, &blocks)) != 0) return rc;
+        if (blocks > ix->num_cus) blocks = ix->num_cus;  // bounds the queue's partial buffer
+        const int64_t stride_q = blocks * k;
+        if ((rc = ensure_buf(&ix->fb_partial, &ix->fb_partial_cap, (int64_t)kTileQ * stride_q)) != 0) return rc;
+        EvScope ev(ix, EV_FINALIZE, st);
+        const float2* bm = slack_q && (ix->per_block & 2) ? ix->bmeta : nullptr;
+        FilterCtl* c = ix->ctl;
+        const dim3 grid((unsigned)(nq + blocks), 1);
+        const size_t lds = (size_t)(kFinThreads / kWave) * 4 * kWave * sizeof(u64);   // the scan role's lists: 8 waves x 4 queries x 64 keys
+#define CODD_FIN_FB(DT, NI)                                                                                                                                    \
+    hipLaunchKernelGGL((finalize_fb_kernel<DT, NI>), grid, dim3(kFinThreads), lds, st, ix->rows, ix->dpad, qn, ix->hits, c->hit_cnt, ix->hit_cap_q, c->flags, k, \
+                       2.0f * eps, row_base, keys_out, ix->dstats, slack_q, (u64*)nullptr, dist_out, rows_out, bm, nq, n, ix->fb_partial, stride_q, &c->fb_done)
+#define CODD_FIN_FB_NI(DT)                          \
+    switch (niter) {                                \
+        case 1: CODD_FIN_FB(DT, 1); break;          \
+        case 2: CODD_FIN_FB(DT, 2); break;          \
+        case 3: CODD_FIN_FB(DT, 3); break;          \
+        case 4: CODD_FIN_FB(DT, 4); break;          \
+        default: return fail(CODD_KNN_ENOTSUP, "row too wide for the finalize kernel%s"); \
+    }
+        if (ix->dtype == DT_F32) { CODD_FIN_FB_NI(DT_F32) }
+        else if (ix->dtype == DT_BF16) { CODD_FIN_FB_NI(DT_BF16) }
+        else { CODD_FIN_FB_NI(DT_F16) }
+#undef CODD_FIN_FB_NI
+#undef CODD_FIN_FB
+        HIP_TRY(hipGetLastError());
+        return CODD_KNN_OK;
+    }
     {
         EvScope ev(ix, EV_FINALIZE, st);
         switch (ix->dtype) {
@@ -1622,6 +1942,94 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     return CODD_KNN_OK;
 }
 
+// ---- one launch for a single query (small_batch_kernel) + the (normally empty) list-driven fallback scan ----
+template <int DT, int NS>
+void launch_small_batch(int64_t nunits, hipStream_t st, const codd_knn_index* ix, const float* dev_queries, int k, uint32_t row_base, u64* cand,
+                        u64* out_keys, float* out_dist, int64_t* out_rows) {
+    constexpr int E = DT == DT_F32 ? 4 : 8;
+    constexpr int NITER = (NS * 128 / E + kWave - 1) / kWave;  // chunks of the PADDED row per lane (dpad <= NS * 128)
+    constexpr int kWavesPerWg = kSbThreads / kWave;
+    // one round of workgroups: as many as are resident at once (the last one to arrive answers the query)
+    static std::atomic<int> per_cu{0};
+    int nb = per_cu.load(std::memory_order_relaxed);
+    if (nb == 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)&small_batch_kernel<DT, NITER, NS>, kSbThreads, 0) != hipSuccess || nb < 1) nb = 1;
+        if (nb > 2) nb = 2;
+        (void)hipGetLastError();
+        per_cu.store(nb, std::memory_order_relaxed);
+    }
+    int64_t G = (int64_t)nb * ix->num_cus;
+    if (G * kWavesPerWg > nunits) G = (nunits + kWavesPerWg - 1) / kWavesPerWg;
+    const dim3 grid((unsigned)G);
+    u64* dropmax = cand + G * kWavesPerWg * kSbKeep;
+    FilterCtl* c = ix->ctl;
+    hipLaunchKernelGGL((small_batch_kernel<DT, NITER, NS>), grid, dim3(kSbThreads), 0, st, ix->shadow8, ix->bmeta, ix->rows, ix->count, ix->dim, ix->dpad,
+                       dev_queries, k, row_base, ix->eps_r_bits, ix->qn, cand, dropmax, &c->sb_ticket, &c->fb_count, c->fb_list, out_keys, out_dist, out_rows,
+                       ix->dstats);
+}
+template <int DT>
+bool launch_small_batch_ns(int ns, int64_t nunits, hipStream_t st, const codd_knn_index* ix, const float* dev_queries, int k, uint32_t row_base, u64* cand,
+                           u64* out_keys, float* out_dist, int64_t* out_rows) {
+    switch (ns) {
+        case 3: launch_small_batch<DT, 3>(nunits, st, ix, dev_queries, k, row_base, cand, out_keys, out_dist, out_rows); return true;
+        case 4: launch_small_batch<DT, 4>(nunits, st, ix, dev_queries, k, row_base, cand, out_keys, out_dist, out_rows); return true;
+        case 6: launch_small_batch<DT, 6>(nunits, st, ix, dev_queries, k, row_base, cand, out_keys, out_dist, out_rows); return true;
+        case 8: launch_small_batch<DT, 8>(nunits, st, ix, dev_queries, k, row_base, cand, out_keys, out_dist, out_rows); return true;
+        default: return false;
+    }
+}
+bool small_batch_applies(const codd_knn_index* ix, int B, int k) {
+    const int ns = dpad8_of(ix) / 128;
+    return ix->small_batch_max > 0 && B == 1 && k <= kWave && (ns == 3 || ns == 4 || ns == 6 || ns == 8) && ix->count >= 4096;
+}
+int small_batch_search(codd_knn_index* ix, const float* dev_queries, int B, int k, uint32_t row_base, u64* out_keys, float* out_dist, int64_t* out_rows,
+                       hipStream_t st) {
+    (void)B;
+    const int ns = dpad8_of(ix) / 128;
+    const int64_t n = ix->count;
+    constexpr int kWavesPerWg = kSbThreads / kWave;
+    const int64_t nunits = (n + 15) / 16;
+    int rc;
+    if ((rc = ensure_buf(&ix->sb_cand, &ix->sb_cand_cap, (int64_t)(2 * ix->num_cus) * kWavesPerWg * (kSbKeep + 1))) != 0) return rc;
+    u64* cand = ix->sb_cand;
+    ix->stat_small_batch++;
+    {
+        EvScope ev(ix, EV_FILTER, st);
+        bool ok;
+        switch (ix->dtype) {
+            case DT_F32: ok = launch_small_batch_ns<DT_F32>(ns, nunits, st, ix, dev_queries, k, row_base, cand, out_keys, out_dist, out_rows); break;
+            case DT_BF16: ok = launch_small_batch_ns<DT_BF16>(ns, nunits, st, ix, dev_queries, k, row_base, cand, out_keys, out_dist, out_rows); break;
+            default: ok = launch_small_batch_ns<DT_F16>(ns, nunits, st, ix, dev_queries, k, row_base, cand, out_keys, out_dist, out_rows); break;
+        }
+        if (!ok) return fail(CODD_KNN_EINVAL, "small batch: unsupported row width%s");
+    }
+    HIP_TRY(hipGetLastError());
+    // a query the margin test could not clear (normally none): the list-driven exact scan, its last block merges
+    {
+        int nit;
+        int64_t blocks;
+        if ((rc = scan_geometry(ix, n, &nit, &blocks)) != 0) return rc;
+        if (blocks > ix->num_cus) blocks = ix->num_cus;
+        const int64_t stride_q = blocks * k;
+        if ((rc = ensure_buf(&ix->fb_partial, &ix->fb_partial_cap, (int64_t)kTileQ * stride_q)) != 0) return rc;
+        ScanArgs a{ix->rows, n, ix->dpad, ix->qn, 0, k, row_base, ix->fb_partial, stride_q, ix->ctl->fb_list, &ix->ctl->fb_count};
+        a.merge_done = &ix->ctl->fb_done;
+        a.merged_keys = out_keys;
+        a.merged_dist = out_dist;
+        a.merged_rows = out_rows;
+        a.count_total = &ix->dstats[2];
+        EvScope ev(ix, EV_SCAN, st);
+        switch (ix->dtype) {
+            case DT_F32: rc = launch_scan_nb<DT_F32>(8, nit, 1, dim3((unsigned)blocks), st, a); break;
+            case DT_BF16: rc = launch_scan_nb<DT_BF16>(8, nit, 1, dim3((unsigned)blocks), st, a); break;
+            default: rc = launch_scan_nb<DT_F16>(8, nit, 1, dim3((unsigned)blocks), st, a); break;
+        }
+        if (rc != 0) return rc;
+        HIP_TRY(hipGetLastError());
+    }
+    return CODD_KNN_OK;
+}
+
 bool filter_applies(const codd_knn_index* ix, int B, int k) {
     // the thresholds come from the k-th largest of the sampled tile maxima: need comfortably more tiles than k
     const int64_t ntiles = (ix->count + kTileRows - 1) / kTileRows;
@@ -1631,6 +2039,24 @@ bool filter_applies(const codd_knn_index* ix, int B, int k) {
     // it is sound for; up to 8 queries the exact scan's single launch wins until rows * B reaches ~100k
     if (B >= ix->filter_min_batch) return ix->count >= ix->filter_min_rows;
     return ix->count * (int64_t)B >= ix->filter_min_rows_small;
+}
+
+// the index looks at its own device counters now and then (one look in flight; after its first 32 searches only every 8th:
+// the copy is a launch of its own on the searching stream)
+int after_filter_search(codd_knn_index* ix, int B, bool use8, hipStream_t st) {
+    (use8 ? ix->watch_q8 : ix->watch_q16) += B;
+    if (ix->shadow8_enabled && !ix->watch_pending && ix->dstats && (ix->stat_searches <= 32 || (ix->stat_searches & 7) == 0)) {
+        if (!ix->watch_host) {
+            HIP_TRY(hipHostMalloc((void**)&ix->watch_host, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&ix->watch_copied, hipEventDisableTiming));
+        }
+        HIP_TRY(hipMemcpyAsync(ix->watch_host, ix->dstats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(ix->watch_copied, st));
+        ix->watch_pending = true;
+        ix->watch_q8_sent = ix->watch_q8;
+        ix->watch_q16_sent = ix->watch_q16;
+    }
+    return CODD_KNN_OK;
 }
 
 // the whole shard-local search: normalise queries, then filter passes or exact scans, keys out.
@@ -1649,7 +2075,10 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
     if ((rc = wait_rows(ix, st)) != 0) return rc;
     bool use_filter = n > 0 && filter_applies(ix, B, k);
     if (ix->eps_r_copied) {
-        if (hipEventQuery(ix->eps_r_copied) == hipSuccess) ix->eps_r_known = *ix->eps_r_host;
+        if (hipEventQuery(ix->eps_r_copied) == hipSuccess) {
+            ix->eps_r_known = ix->eps_r_host[0];
+            ix->wide_blocks_known = (int64_t)reinterpret_cast<const unsigned*>(ix->eps_r_host)[1];
+        }
         else (void)hipGetLastError();  // "not ready" must not surface in a later error check
     }
     if (ix->watch_pending && ix->watch_copied) {
@@ -1661,13 +2090,16 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
                 if ((per_q > (double)ix->shadow8_max_surv || (fb - ix->watch_fb) * 20 > (unsigned long long)ix->watch_q8_sent) &&
                     ix->cooldown_useless_epoch != ix->epoch) {
                     ix->cooldown_left = ix->shadow8_cooldown;
+                    ix->cooldown_surv8 = per_q;  // what the 2-byte filter has to beat
                     ix->stat_cooldowns++;
                 }
             } else if (ix->watch_q16_sent > 0 && ix->watch_q8_sent == 0) {
                 // only bf16 passes (a cooldown): when those leave the re-scoring just as crowded — rows closer to each other than
                 // EITHER slack — the slower bf16 kernel buys nothing: stay on int8 until rows change
+                // (relative, not absolute: the fp16 filter's passes cost about twice an int8 pass, so they pay as soon as they
+                // leave well under half of the exact re-scoring — 7,000 survivors per query are a bargain against 62,000)
                 const double per_q = (double)(surv - ix->watch_surv) / (double)ix->watch_q16_sent;
-                if (per_q > (double)ix->shadow8_max_surv) {
+                if (per_q > (double)ix->shadow8_max_surv && per_q > 0.5 * ix->cooldown_surv8) {
                     ix->cooldown_useless_epoch = ix->epoch;
                     ix->cooldown_left = 0;
                 }
@@ -1684,7 +2116,13 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
     if (cooling && use_filter) ix->cooldown_left--;
     // the int8 filter: every pass of <= 256 queries prepares its own block (a batch above 256 queries is several passes)
     const bool can8 = use_filter && ix->shadow8_enabled && (B <= ix->shadow8_max_batch || (B > kTileQ && ix->shadow8_max_batch >= kTileQ)) && CODD_MFMA16;
-    bool use8 = can8 && !cooling && ix->eps_r_known <= ix->shadow8_max_eps;
+    // A corpus whose WORST block quantises badly keeps the int8 filter for the batches i8_tile_kernel takes as long as such blocks are
+    // rare (under 1 %): that kernel and finalize evaluate the bound per 32-row block, so only the bad blocks' rows come through
+    // as extra candidates.  The first-generation kernels (other batch sizes, rows under 384 elements) use the device-wide bound.
+    const int nsteps8 = dpad8_of(ix) / 128;
+    const bool per_block = ix->i8v2 != 0 && nsteps8 >= 3 && B > 64 && (B <= 128 ? ix->i8v2_half != 0 : B <= kTileQ) && (ix->i8v2 == 2 || nsteps8 > 4 || !ix->resident_q);
+    const bool eps_ok = ix->eps_r_known <= ix->shadow8_max_eps || (per_block && ix->wide_blocks_known * 100 <= (ix->count + 31) / 32);
+    bool use8 = can8 && !cooling && eps_ok;
     if (use_filter && !use8) {
         // the bf16 filter: its shadow is allocated by the first search that needs it.  When HBM cannot hold it the search is
         // still answered exactly — through the int8 filter where the index may use it (a cooldown or a wide eps_r only make
@@ -1710,8 +2148,15 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
     if (use8) {
         if ((rc = ensure_filter_workspace(ix)) != 0) return rc;
         if ((rc = ensure_shadow8(ix, st)) != 0) return rc;
+        // a handful of queries: ONE launch streams the int8 shadow, keeps the best approximate scores per wave and re-scores the
+        // survivors exactly in its last workgroup (small_batch_kernel) instead of the six-launch filter chain
+        if (small_batch_applies(ix, B, k)) {
+            if ((rc = ensure_buf(&ix->qn, &ix->qn_cap, (int64_t)B * ix->dpad)) != 0) return rc;
+            if ((rc = small_batch_search(ix, dev_queries, B, k, row_base, out_keys, out_dist, out_rows, st)) != 0) return rc;
+            return after_filter_search(ix, B, true, st);
+        }
         if ((rc = ensure_buf(&ix->qfrag8, &ix->qfrag8_cap, (int64_t)kTileQ * (dpad8 / 16))) != 0) return rc;
-        if (!ix->qmeta) HIP_TRY(hipMalloc((void**)&ix->qmeta, 512 * sizeof(float)));
+        if (!ix->qmeta) HIP_TRY(hipMalloc((void**)&ix->qmeta, 1024 * sizeof(float)));
     } else if (fused_prep) {
         hipLaunchKernelGGL(prep_queries_kernel, dim3(kTileQ / 4), dim3(256), 0, st, dev_queries, B, ix->dim, ix->dpad, ix->qn,
                            reinterpret_cast<uint2*>(ix->qfrag), reinterpret_cast<unsigned*>(ix->ctl), (int)(sizeof(FilterCtl) / 4));
@@ -1740,21 +2185,7 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
                               fused_prep || use8, use8)) != 0)
             return rc;
     }
-    (use8 ? ix->watch_q8 : ix->watch_q16) += B;
-    // the index looks at its own device counters now and then (one look in flight; after its first 32 searches only every 8th:
-    // the copy is a launch of its own on the searching stream)
-    if (ix->shadow8_enabled && !ix->watch_pending && ix->dstats && (ix->stat_searches <= 32 || (ix->stat_searches & 7) == 0)) {
-        if (!ix->watch_host) {
-            HIP_TRY(hipHostMalloc((void**)&ix->watch_host, 4 * sizeof(unsigned long long), hipHostMallocDefault));
-            HIP_TRY(hipEventCreateWithFlags(&ix->watch_copied, hipEventDisableTiming));
-        }
-        HIP_TRY(hipMemcpyAsync(ix->watch_host, ix->dstats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipEventRecord(ix->watch_copied, st));
-        ix->watch_pending = true;
-        ix->watch_q8_sent = ix->watch_q8;
-        ix->watch_q16_sent = ix->watch_q16;
-    }
-    return CODD_KNN_OK;
+    return after_filter_search(ix, B, use8, st);
 }
 
 }  // namespace
@@ -1805,7 +2236,7 @@ int codd_knn_destroy(codd_knn_index* ix) {
     if (!ix) return CODD_KNN_OK;
     DeviceGuard guard(ix->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = {ix->rows, ix->shadow, ix->dstats, ix->rows_ivf, ix->ivf_ids, ix->ivf_offsets, ix->shadow8, ix->rscale, ix->eps_r_bits};
+    void* bufs[] = {ix->rows, ix->shadow, ix->dstats, ix->rows_ivf, ix->ivf_ids, ix->ivf_offsets, ix->shadow8, ix->rscale, ix->bmeta, ix->eps_r_bits};
     if (ix->shadow8_ready) (void)hipEventDestroy(ix->shadow8_ready);
     if (ix->shadow_ready) (void)hipEventDestroy(ix->shadow_ready);
     if (ix->rows_ready) (void)hipEventDestroy(ix->rows_ready);
@@ -1820,7 +2251,7 @@ int codd_knn_destroy(codd_knn_index* ix) {
         if (b) (void)hipFree(b);
     for (WorkSlot& w : ix->slots) {
         void* wb[] = {w.bufs.qn, w.bufs.partial, w.bufs.keys_tmp, w.bufs.qfrag, w.bufs.thr, w.bufs.bucket_max, w.bufs.hits, w.bufs.ctl,
-                      w.bufs.fb_partial, w.bufs.probe_keys, w.bufs.ivf_partial, w.bufs.qfrag8, w.bufs.qmeta};
+                      w.bufs.fb_partial, w.bufs.probe_keys, w.bufs.ivf_partial, w.bufs.qfrag8, w.bufs.qmeta, w.bufs.sb_cand};
         for (void* b : wb)
             if (b) (void)hipFree(b);
         if (w.handover) (void)hipEventDestroy(w.handover);
@@ -2038,7 +2469,7 @@ int codd_knn_approx_scores(codd_knn_index* ix, const float* dev_queries, int B, 
         if ((rc = ensure_shadow8(ix, st)) != 0) return rc;
         const int dpad8 = dpad8_of(ix);
         if ((rc = ensure_buf(&ix->qfrag8, &ix->qfrag8_cap, (int64_t)kTileQ * (dpad8 / 16))) != 0) return rc;
-        if (!ix->qmeta) HIP_TRY(hipMalloc((void**)&ix->qmeta, 512 * sizeof(float)));
+        if (!ix->qmeta) HIP_TRY(hipMalloc((void**)&ix->qmeta, 1024 * sizeof(float)));
         hipLaunchKernelGGL(prep_queries8_kernel, dim3(kTileQ / 4), dim3(256), 0, st, dev_queries, B, ix->dim, ix->dpad, dpad8, ix->qn,
                            reinterpret_cast<uint32_t*>(ix->qfrag8), ix->qmeta, ix->eps_r_bits, reinterpret_cast<unsigned*>(ix->ctl),
                            (int)(sizeof(FilterCtl) / 4), 1.0f);
@@ -2212,6 +2643,19 @@ int codd_knn_ivf_search(codd_knn_index* ix, const float* dev_queries, int B, int
     return launch_merge(ix->ivf_partial, B, m, m, k, (u64*)dev_keys, dev_dist, dev_rows, st);
 }
 
+#ifdef CODD_I8_EXP_STAMPS
+// diagnostic builds only (not in include/codd_knn.h): the per-wave phase stamps of the last i8_tile_kernel<FILTER> launch on `stream`'s
+// workspace — [workgroup][wave][8] u64: issue, corpus wait, MFMA phase, end-of-interval sync, epilogue, intervals, total, tiles
+int codd_knn_exp_read_stamps(codd_knn_index* ix, unsigned long long* host_out, int n_u64, void* stream) {
+    if (!ix || !host_out) return CODD_KNN_EINVAL;
+    WorkScope work(ix, (hipStream_t)stream);
+    if (!ix->bucket_max || (int64_t)n_u64 > ix->bucket_cap) return CODD_KNN_EINVAL;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(host_out, ix->bucket_max, (size_t)n_u64 * 8, hipMemcpyDeviceToHost));
+    return CODD_KNN_OK;
+}
+#endif
+
 int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {
     if (!ix || !key) return fail(CODD_KNN_EINVAL, "bad option arguments%s");
     if (strcmp(key, "scan_blocks_per_cu") == 0) {
@@ -2266,6 +2710,26 @@ int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {
     if (strcmp(key, "i8v2") == 0) {
         if (value < 0 || value > 2) return fail(CODD_KNN_EINVAL, "i8v2 must be 0, 1 or 2%s");
         ix->i8v2 = (int)value;
+        return CODD_KNN_OK;
+    }
+    if (strcmp(key, "fuse_fallback") == 0) {
+        if (value != 0 && value != 1) return fail(CODD_KNN_EINVAL, "fuse_fallback must be 0 or 1%s");
+        ix->fuse_fallback = (int)value;
+        return CODD_KNN_OK;
+    }
+    if (strcmp(key, "small_batch_max") == 0) {
+        if (value < 0 || value > 1) return fail(CODD_KNN_EINVAL, "small_batch_max must be 0 or 1%s");
+        ix->small_batch_max = (int)value;
+        return CODD_KNN_OK;
+    }
+    if (strcmp(key, "per_block") == 0) {
+        if (value < 0 || value > 7) return fail(CODD_KNN_EINVAL, "per_block must be in [0,7]%s");
+        ix->per_block = (int)value;
+        return CODD_KNN_OK;
+    }
+    if (strcmp(key, "i8_pair") == 0) {
+        if (value != 0 && value != 1) return fail(CODD_KNN_EINVAL, "i8_pair must be 0 or 1%s");
+        ix->i8_pair = (int)value;
         return CODD_KNN_OK;
     }
     if (strcmp(key, "i8v2_half") == 0) {
@@ -2356,9 +2820,17 @@ int codd_knn_get_stat(const codd_knn_index* ix, const char* key, int64_t* out) {
     else if (strcmp(key, "all_normalized") == 0) *out = ix->all_normalized ? 1 : 0;
     else if (strcmp(key, "shadow8_passes") == 0) *out = ix->stat_shadow8_passes;
     else if (strcmp(key, "i8v2_passes") == 0) *out = ix->stat_i8v2_passes;
+    else if (strcmp(key, "small_batch_passes") == 0) *out = ix->stat_small_batch;
     else if (strcmp(key, "shadow8_cooldowns") == 0) *out = ix->stat_cooldowns;
+    else if (strcmp(key, "shadow8_wide_blocks") == 0) {  // blocks whose error norm exceeds shadow8_max_eps, as last read back
+        if (ix->eps_r_copied && hipEventQuery(ix->eps_r_copied) == hipSuccess) *out = (int64_t)reinterpret_cast<const unsigned*>(ix->eps_r_host)[1];
+        else {
+            (void)hipGetLastError();
+            *out = ix->wide_blocks_known;
+        }
+    }
     else if (strcmp(key, "shadow8_eps_r_micro") == 0) {  // worst row's quantisation error norm x 1e6, as last read back
-        if (ix->eps_r_copied && hipEventQuery(ix->eps_r_copied) == hipSuccess) *out = (int64_t)(*ix->eps_r_host * 1e6f);
+        if (ix->eps_r_copied && hipEventQuery(ix->eps_r_copied) == hipSuccess) *out = (int64_t)(ix->eps_r_host[0] * 1e6f);
         else {
             (void)hipGetLastError();
             *out = (int64_t)(ix->eps_r_known * 1e6f);

@@ -36,7 +36,10 @@
 namespace codd {
 
 #ifndef CODD_SHADOW_F16
-#define CODD_SHADOW_F16 0    // 1: the filter's operands are fp16 (11-bit significand: eps ~4x tighter) instead of bf16
+#define CODD_SHADOW_F16 1    // the 2-byte shadow's element type: 1 = fp16 (11-bit significand: eps 0.0011 at 768-d), 0 = bf16 (8 bits: eps 0.0079).
+                             // Same MFMA rate, same bytes; fp16 since round 3: this filter is what an index falls back to when the int8 one (eps ~0.02)
+                             // cannot separate a query's neighbourhood from the rest of a dense cluster, and there a 7x tighter slack is worth more than
+                             // anything else (profiles/r3/clustered_corpora.txt).  Unit-norm operands cannot overflow fp16; its subnormal grid is in the bound.
 #endif
 #if CODD_SHADOW_F16
 typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8;  // "shadow element x8" (name kept for the bf16 default)
@@ -773,18 +776,18 @@ constexpr int kSurvChunk = 2048;  // hits examined per round; their survivors al
 constexpr int kFinWaves = CODD_FIN_WAVES;      // waves of a finalize workgroup (one query, or one share of its hits): the kernel is a chain of
 constexpr int kFinThreads = kFinWaves * kWave; // round trips (hit list, k anchor rows, survivor rows), so a query gets as many waves as pay
 
+// finalize_body: what one workgroup of kFinThreads threads does for ONE query (or one share of its candidates): `my[0, total)`
+// are the query's candidate keys (approximate score, local row; 0 = empty slot), qn_q its normalised fp32 vector.
+//   eps1 : the slack between an approximate and an exact score — the whole of it, or (bmeta != nullptr, the int8 filter) its
+//          block-independent part A(q), with bq = B(q): eps(q, block) = A + B e_block, e_block = bmeta[row / 32].y
+//   out_*_q / part_keys_q : where this query's k results go (any may be null)
+// Shared by finalize_kernel and by the last workgroup of small_batch_kernel (codd_knn.hip).
 template <int DT, int NITER, int SLOTS>
-__global__ __launch_bounds__(kFinThreads) void finalize_kernel(const void* __restrict__ rows_, int dpad, const float* __restrict__ qn,
-                                                       const u64* __restrict__ hits, const unsigned* __restrict__ hit_cnt,
-                                                       int cap_q, unsigned* __restrict__ flags, int k, float two_eps,
-                                                       uint32_t row_base, u64* __restrict__ out_keys,
-                                                       unsigned* __restrict__ fb_count, unsigned* __restrict__ fb_list,
-                                                       unsigned long long* __restrict__ stats, const float* __restrict__ two_eps_q = nullptr,
-                                                       u64* __restrict__ part_keys = nullptr, float* __restrict__ out_dist = nullptr,
-                                                       int64_t* __restrict__ out_rows = nullptr) {
-    // gridDim.y > 1: the query's hit list is shared out between gridDim.y workgroups (contiguous shares), each
-    // writes its own top-k to part_keys[(q * P + p) * k ..] and a merge launch follows.  With one or a few queries
-    // and thousands of survivors (the int8 filter) one workgroup per query would do all the re-scoring on one CU.
+__device__ __forceinline__ void finalize_body(const void* __restrict__ rows_, int dpad, const float* __restrict__ qn_q, const u64* __restrict__ my,
+                                              unsigned total, unsigned part, unsigned nparts, int k, float eps1, float bq,
+                                              const float2* __restrict__ bmeta, uint32_t row_base, u64* __restrict__ out_keys_q,
+                                              float* __restrict__ out_dist_q, int64_t* __restrict__ out_rows_q, u64* __restrict__ part_keys_q,
+                                              unsigned long long* __restrict__ stats, float* lo_out = nullptr) {
     typedef RowTraits<DT> RT;
     constexpr int E = RT::E;
     __shared__ u64 lds_list[kFinWaves * SLOTS * kWave];
@@ -793,17 +796,7 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(const void* __res
     __shared__ float lds_lo;
     __shared__ float lds_anchor[kFinWaves];
 
-    const int q = blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned total = hit_cnt[q * kHitCntStride];
-    const unsigned part = blockIdx.y, nparts = gridDim.y;
-    if (total > (unsigned)cap_q) {  // the candidate list was truncated: only the exact scan can answer this query
-        if (tid == 0 && part == 0) {
-            fb_list[atomicAdd(fb_count, 1u)] = (unsigned)q;
-            atomicOr(&flags[FLAG_NEED_FALLBACK], 1u);
-        }
-        return;
-    }
-    const u64* my = hits + (int64_t)q * cap_q;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // the query's fragments for the exact re-scoring: requested first, so the round trip overlaps step 1
     const int nchunks = dpad / E;
@@ -812,7 +805,7 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(const void* __res
     for (int it = 0; it < NITER; ++it) {
         const int j = lane + kWave * it;
 #pragma unroll
-        for (int e = 0; e < E; ++e) qf[it][e] = j < nchunks ? qn[(int64_t)q * dpad + (int64_t)j * E + e] : 0.0f;
+        for (int e = 0; e < E; ++e) qf[it][e] = j < nchunks ? qn_q[(int64_t)j * E + e] : 0.0f;
     }
 
     // 1. k-th largest approximate key
@@ -889,11 +882,11 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(const void* __res
         if (lane == 0) lds_anchor[wave] = worst;
         __syncthreads();
         if (tid == 0) {
-            const float eps1 = 0.5f * (two_eps_q ? two_eps_q[blockIdx.x] : two_eps);
             float l4 = lds_anchor[0];
 #pragma unroll
             for (int wv = 1; wv < kFinWaves; ++wv) l4 = fminf(l4, lds_anchor[wv]);
             lds_lo = nk ? l4 - eps1 : -INFINITY;
+            if (lo_out) *lo_out = lds_lo;
         }
         __syncthreads();
     }
@@ -913,7 +906,8 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(const void* __res
         const unsigned b1 = b0 + kSurvChunk < my_hi ? b0 + kSurvChunk : my_hi;
         for (unsigned i = b0 + tid; i < b1; i += kFinThreads) {
             const u64 key = my[i];
-            if (key_score(key) >= lo) lds_surv[atomicAdd(&lds_n, 1u)] = key_row(key);
+            const float slack_b = bmeta ? bq * bmeta[key_row(key) >> 5].y : 0.0f;
+            if (key_score(key) + slack_b >= lo) lds_surv[atomicAdd(&lds_n, 1u)] = key_row(key);
         }
         __syncthreads();
         const unsigned ns = lds_n;
@@ -949,29 +943,63 @@ __global__ __launch_bounds__(kFinThreads) void finalize_kernel(const void* __res
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) lds_list[(wave * SLOTS + s) * kWave + lane] = X.v[s];
     __syncthreads();
-    if (wave != 0) return;
-    for (int wv = 1; wv < kFinWaves; ++wv)
+    if (wave == 0) {
+        for (int wv = 1; wv < kFinWaves; ++wv)
+#pragma unroll
+            for (int s = 0; s < SLOTS; ++s) {
+                u64 cand = lds_list[(wv * SLOTS + s) * kWave + lane];
+                if (s * kWave + lane >= k) cand = 0ull;
+                X.offer_lanes(cand, k, lane);
+            }
 #pragma unroll
         for (int s = 0; s < SLOTS; ++s) {
-            u64 cand = lds_list[(wv * SLOTS + s) * kWave + lane];
-            if (s * kWave + lane >= k) cand = 0ull;
-            X.offer_lanes(cand, k, lane);
-        }
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        const int rank = s * kWave + lane;
-        if (rank < k) {
-            const u64 key = X.v[s];
-            if (nparts > 1) {
-                part_keys[((int64_t)q * nparts + part) * k + rank] = key;
-            } else {
-                // the caller's (distance, row) outputs straight from here: no unpack launch behind the pass
-                if (out_keys) out_keys[(int64_t)q * k + rank] = key;
-                if (out_dist) out_dist[(int64_t)q * k + rank] = key ? 1.0f - key_score(key) : INFINITY;
-                if (out_rows) out_rows[(int64_t)q * k + rank] = key ? (int64_t)key_row(key) : (int64_t)-1;
+            const int rank = s * kWave + lane;
+            if (rank < k) {
+                const u64 key = X.v[s];
+                if (nparts > 1) {
+                    part_keys_q[rank] = key;
+                } else {
+                    // the caller's (distance, row) outputs straight from here: no unpack launch behind the pass
+                    if (out_keys_q) out_keys_q[rank] = key;
+                    if (out_dist_q) out_dist_q[rank] = key ? 1.0f - key_score(key) : INFINITY;
+                    if (out_rows_q) out_rows_q[rank] = key ? (int64_t)key_row(key) : (int64_t)-1;
+                }
             }
         }
     }
+    __syncthreads();  // (a caller that loops over queries reuses the shared lists)
+}
+
+template <int DT, int NITER, int SLOTS>
+__global__ __launch_bounds__(kFinThreads) void finalize_kernel(const void* __restrict__ rows_, int dpad, const float* __restrict__ qn,
+                                                       const u64* __restrict__ hits, const unsigned* __restrict__ hit_cnt,
+                                                       int cap_q, unsigned* __restrict__ flags, int k, float two_eps,
+                                                       uint32_t row_base, u64* __restrict__ out_keys,
+                                                       unsigned* __restrict__ fb_count, unsigned* __restrict__ fb_list,
+                                                       unsigned long long* __restrict__ stats, const float* __restrict__ two_eps_q = nullptr,
+                                                       u64* __restrict__ part_keys = nullptr, float* __restrict__ out_dist = nullptr,
+                                                       int64_t* __restrict__ out_rows = nullptr, const float2* __restrict__ bmeta = nullptr) {
+    // bmeta (int8 filter; two_eps_q = qmeta + 256): the slack is evaluated per 32-row block, eps(q, block) = A(q) + B(q) e_block
+    // (A at two_eps_q[256 + q], B at two_eps_q[512 + q], e_block = bmeta[row / 32].y): a hit survives iff
+    // approx + B e_block >= L' - A.  Valid whichever kernel wrote the hit list (every kernel's list holds these rows).
+    // gridDim.y > 1: the query's hit list is shared out between gridDim.y workgroups (contiguous shares), each
+    // writes its own top-k to part_keys[(q * P + p) * k ..] and a merge launch follows.  With one or a few queries
+    // and thousands of survivors (the int8 filter) one workgroup per query would do all the re-scoring on one CU.
+    const int q = blockIdx.x;
+    const unsigned total = hit_cnt[q * kHitCntStride];
+    const unsigned part = blockIdx.y, nparts = gridDim.y;
+    if (total > (unsigned)cap_q) {  // the candidate list was truncated: only the exact scan can answer this query
+        if (threadIdx.x == 0 && part == 0) {
+            fb_list[atomicAdd(fb_count, 1u)] = (unsigned)q;
+            atomicOr(&flags[FLAG_NEED_FALLBACK], 1u);
+        }
+        return;
+    }
+    const float eps1 = bmeta ? two_eps_q[256 + q] : 0.5f * (two_eps_q ? two_eps_q[q] : two_eps);
+    const float bq = bmeta ? two_eps_q[512 + q] : 0.0f;
+    finalize_body<DT, NITER, SLOTS>(rows_, dpad, qn + (int64_t)q * dpad, hits + (int64_t)q * cap_q, total, part, nparts, k, eps1, bq, bmeta, row_base,
+                                    out_keys ? out_keys + (int64_t)q * k : nullptr, out_dist ? out_dist + (int64_t)q * k : nullptr,
+                                    out_rows ? out_rows + (int64_t)q * k : nullptr, part_keys ? part_keys + ((int64_t)q * nparts + part) * k : nullptr, stats);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -986,7 +1014,10 @@ constexpr int kAnchorWaves = 4;  // waves per query: the bucket scan and the k r
 template <int DT, int NITER, int SLOTS>
 __global__ __launch_bounds__(kAnchorWaves * kWave) void anchor_thr_kernel(const u64* __restrict__ bucket_key, int64_t nbuckets, int B, int k,
                                                                           const void* __restrict__ rows_, int dpad, const float* __restrict__ qn, float eps,
-                                                                          const float* __restrict__ two_eps_q, float* __restrict__ thr) {
+                                                                          const float* __restrict__ two_eps_q, float* __restrict__ thr,
+                                                                          float* __restrict__ thr0 = nullptr) {
+    // thr0 (int8 filter, with two_eps_q = qmeta + 256): L - A(q), the block-independent part of the per-block threshold
+    // L - A(q) - B(q) e_block that i8_tile_kernel evaluates (A at two_eps_q[256 + q])
     typedef RowTraits<DT> RT;
     constexpr int E = RT::E;
     __shared__ u64 lds_list[kAnchorWaves * SLOTS * kWave];  // the waves' lists; then [rank] of the merged one
@@ -994,7 +1025,10 @@ __global__ __launch_bounds__(kAnchorWaves * kWave) void anchor_thr_kernel(const 
     __shared__ int lds_full;
     const int q = blockIdx.x, tid = (int)threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     if (q >= B) {
-        if (tid == 0) thr[q] = INFINITY;
+        if (tid == 0) {
+            thr[q] = INFINITY;
+            if (thr0) thr0[q] = INFINITY;
+        }
         return;
     }
     const int nchunks = dpad / E;
@@ -1028,7 +1062,10 @@ __global__ __launch_bounds__(kAnchorWaves * kWave) void anchor_thr_kernel(const 
     }
     __syncthreads();
     if (!lds_full) {  // fewer than k buckets with a row: no threshold can be justified
-        if (tid == 0) thr[q] = -INFINITY;
+        if (tid == 0) {
+            thr[q] = -INFINITY;
+            if (thr0) thr0[q] = -INFINITY;
+        }
         return;
     }
     const uint4* base = reinterpret_cast<const uint4*>(rows_);
@@ -1089,6 +1126,7 @@ __global__ __launch_bounds__(kAnchorWaves * kWave) void anchor_thr_kernel(const 
 #pragma unroll
         for (int wv = 1; wv < kAnchorWaves; ++wv) wmin = fminf(wmin, lds_worst[wv]);
         thr[q] = wmin - (two_eps_q ? 0.5f * two_eps_q[q] : eps);
+        if (thr0) thr0[q] = wmin - two_eps_q[256 + q];
     }
 }
 

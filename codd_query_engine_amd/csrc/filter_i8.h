@@ -36,7 +36,8 @@
 #include "filter_gemm.h"
 
 #if !CODD_EXPERIMENTS && (defined(CODD_I8_EXP_NOEPI) || defined(CODD_I8_EXP_NODMA) || defined(CODD_I8_EXP_SAMETILE) || defined(CODD_I8_EXP_NOBARRIER) || \
-                          defined(CODD_I8_EXP_NOBREAD) || defined(CODD_I8_EXP_NOHITS) || defined(CODD_I8_EXP_NOAPPEND) || defined(CODD_I8_EXP_NOFLUSH) || defined(CODD_I8_EXP_NOGLOBAL))
+                          defined(CODD_I8_EXP_NOBREAD) || defined(CODD_I8_EXP_NOHITS) || defined(CODD_I8_EXP_NOAPPEND) || defined(CODD_I8_EXP_NOFLUSH) || defined(CODD_I8_EXP_NOGLOBAL) || \
+                          defined(CODD_I8_EXP_STAMPS))
 #error "the CODD_I8_EXP_* switches return wrong results or race: they exist only in -DCODD_EXPERIMENTS=1 builds (build_variant)"
 #endif
 
@@ -49,7 +50,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kI8SliceBytes = 32768;  // one 128-wide K slice of the 256-query block
 constexpr int kI8RsBufs = 2;          // row-scale buffers (tile ordinal & 1): a tile's scales are read (its epilogue, at the start of the next tile) before the tile after next requests its own
 constexpr int kI8RsStride = 272;      // floats per buffer: 256 row scales + 8 per-wave maxima (+ pad)
-#if !CODD_EXPERIMENTS && (defined(CODD_I8_BDEPTH) || defined(CODD_I8_EARLY_FRAGS) || defined(CODD_I8_LAG))
+#if !CODD_EXPERIMENTS && (defined(CODD_I8_BDEPTH) || defined(CODD_I8_EARLY_FRAGS) || defined(CODD_I8_LAG) || defined(CODD_I8_SPREAD_VM) || defined(CODD_I8_FUSE_EPI))
 #error "CODD_I8_BDEPTH / CODD_I8_EARLY_FRAGS / CODD_I8_LAG are schedule experiments: only their defaults are under test; -DCODD_EXPERIMENTS=1 builds (build_variant) may set them"
 #endif
 #ifndef CODD_I8_BDEPTH
@@ -62,11 +63,24 @@ constexpr int kBD = CODD_I8_BDEPTH;
 #ifndef CODD_I8_LAG
 #define CODD_I8_LAG 0                 // 1: waves 4..7 run one K-step behind waves 0..3 (measured 12 % slower twice, profiles/r2/i8_tile_ablation.txt; experiment builds only)
 #endif
+#ifndef CODD_I8_SPREAD_VM
+#define CODD_I8_SPREAD_VM 0           // pair program: 1 = the interval's vector-memory operations are issued one at a time behind MFMA groups instead of in a
+                                      // block in front of them; 2 = ... the SIMD partners taking turns (waves 0..3 behind even groups, 4..7 behind odd ones)
+#endif
 #ifndef CODD_I8_FUSE_EPI
-#define CODD_I8_FUSE_EPI 1            // the tile-structured filter program tests tile i's accumulators INSIDE the first K-step of tile i + 1 (see epi_pair)
+#define CODD_I8_FUSE_EPI 0            // 1: the tile-structured filter program tests tile i's accumulators INSIDE the first K-step of tile i + 1 (epi_pair in front
+                                      // of the MFMAs that restart the pair).  Built, bit-equal, measured 1.7-3 % SLOWER (profiles/r3/i8_tile_ablation.txt): the
+                                      // pre-tests' vector instructions slow the MFMA stream they sit in by as much as the standalone block costs
 #endif
 
 // ---- hand-issued memory operations (see the header) --------------------------------------------------------------
+// HAZARD (found in round 3 as non-deterministic lost neighbours): gfx9 needs 5 wait states between a VALU instruction that
+// WRITES an SGPR (v_readfirstlane, and v_readlane — which is how hipcc reloads the SGPRs this kernel spills to VGPR lanes,
+// 2,400 times in the program) and a vector-memory instruction that READS that SGPR (descriptor, soffset).  hipcc pads its
+// own instructions for this; it does not look inside inline asm.  A descriptor word produced right in front of one of
+// these statements was read STALE: a K-step's corpus fragment came from a wrong address, non-deterministically, and whether
+// it happened depended on register pressure (it appeared with one more live SGPR).  Every statement below therefore
+// carries its own wait states in front of the memory instruction (the s_mov to m0 counts as one).
 // buffer descriptor (4 SGPRs): base, 48-bit address | stride 0, bytes, gfx950 raw-buffer flags; out-of-range reads return 0
 __device__ __forceinline__ i32x4 i8_rsrc(const void* p, unsigned bytes) {
     const unsigned long long a = (unsigned long long)p;
@@ -79,20 +93,26 @@ __device__ __forceinline__ i32x4 i8_rsrc(const void* p, unsigned bytes) {
 }
 template <int OFF>
 __device__ __forceinline__ void i8_load_b128_nt(u32x4& dst, int voff, i32x4 rsrc) {  // read-once stream: non-temporal
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3 nt" : "=v"(dst) : "v"(voff), "s"(rsrc), "n"(OFF));
+    // (s_nop 4: the HAZARD note above)
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3 nt" : "=v"(dst) : "v"(voff), "s"(rsrc), "n"(OFF));
 }
+// (m0 is on the clobber lists: hipcc reserves it for its own implicit uses — each is preceded by its own s_mov m0 — and warns that a
+// reserved register "may not be preserved"; listing it is what keeps its scheduler from placing these statements between such a pair)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 // 64 lanes x 16 bytes: global (rsrc + voff + soff) -> LDS [lds_addr + 16 * lane]
 __device__ __forceinline__ void i8_dma_b128(unsigned lds_addr, int voff, i32x4 rsrc, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rsrc),
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rsrc),
                  "s"(__builtin_amdgcn_readfirstlane(soff))
                  : "memory", "m0");
 }
 // 64 lanes x 4 bytes: global (rsrc + voff + soff) -> LDS [lds_addr + 4 * lane]
 __device__ __forceinline__ void i8_dma_b32(unsigned lds_addr, int voff, i32x4 rsrc, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rsrc),
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rsrc),
                  "s"(__builtin_amdgcn_readfirstlane(soff))
                  : "memory", "m0");
 }
+#pragma clang diagnostic pop
 template <int N>
 __device__ __forceinline__ void i8_wait_vm(u32x4& a, u32x4& b, u32x4& c, u32x4& d) {
     asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
@@ -110,13 +130,19 @@ __device__ __forceinline__ void lgkm_wait_asm(i32x4& v) {
     asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(v) : "n"(N));
 }
 
+__device__ __forceinline__ float i8_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
 // vector-memory operations per interval, in issue order: scale DMA, kDmaPerIv slice DMA, kAPerIv corpus loads
 // (kDmaPerIv = NQB / 4: a slice of 16 NQB queries is NQB / 2 chunks of 1 KiB per wave pair... 2 NQB KiB in all, 8 waves)
 constexpr int kAPerIv = 4;
 // bookkeeping words behind the slices: [0..127] pre-test thresholds, two bf16 per word (layout: the kernel's set-up); [256], [257] hit counts;
-// [320..575] query scales; [576..831] exact thresholds (thr / qscale), by query; [832..1087] scratch of the in-loop flush.
+// [260..263] the waves' maxima of u_q; [320..575] query scales; [576..831] exact thresholds (thr0 / qscale), by query; [832..1087] scratch of the in-loop flush.
 // SAMPLE: [0..511] = 256 u64 keys.
-constexpr int kI8Words = 1088;
+constexpr int kI8Words = 1344;   // ... [1088..1343] u_q = B(q) / qscale_q (FILTER)
 
 // does the resident program apply? (nbq: 32-query blocks of the batch: 8 -> NQB = 16, 4 -> NQB = 8)
 __host__ __device__ constexpr bool i8_tile_resident(int nsteps, int nbq) { return nsteps <= (nbq == 8 ? 4 : 8); }
@@ -131,13 +157,27 @@ __host__ __device__ constexpr size_t i8_lds_bytes(int mode) {
 // RES: the whole query block fits the four LDS slices (rows of <= 4 K-steps; <= 8 K-steps with 8 query blocks, whose slices
 // are half as big): every workgroup loads it once and no slice is re-staged per tile (the host picks it: i8_tile_resident();
 // LAG builds keep the staged program).
-template <int MODE, bool STEPS3, int NQB = 16, bool RES = false>
+// TS (tile structure; the host picks it): 0 = generic interval loop; 1 = rows whose K-steps are a multiple of 3 (tiles start at
+// corpus-ring phase 0: the tile-structured program, "STEPS3"); 2 = ... a multiple of 6 (768 elements), staged slices: the same
+// program with ONE workgroup barrier per TWO K-steps.  The four LDS slices hold the two slices being read and the two
+// landing; the barrier behind every odd K-step hands both pairs over at once (the barrier behind an even K-step protected
+// nothing that the next one does not: slot (t + 2) & 3, requested during step t, was last read during step t - 2).
+template <int MODE, int TS, int NQB = 16, bool RES = false>
 __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict__ shadow8, const uint4* __restrict__ qfrag8, int64_t n, int nsteps,
                                                          int64_t ntiles_run, int64_t tile_stride, const float* __restrict__ thr,
                                                          u64* __restrict__ bucket_key, u64* __restrict__ hits, unsigned* __restrict__ hit_cnt,
                                                          int cap_q, unsigned* __restrict__ flags, const float* __restrict__ rscale,
-                                                         const float* __restrict__ qscale) {
+                                                         const float* __restrict__ qscale, const float2* __restrict__ bmeta = nullptr, float eb_scale = 1.0f) {
+    // FILTER: `thr` holds thr0[q] = L(q) - A(q) and qscale[768 + q] = B(q): the bound is evaluated per 32-row block,
+    // eps(q, block) = A(q) + B(q) * e_block with e_block = bmeta[block].y, the block's own quantisation error norm (its scale is
+    // bmeta[block].x).  A row of block b is a candidate iff acc * scale_b * qscale_q >= thr0[q] - B(q) e_b, i.e. (in the units
+    // the tests run in) acc * scale_b + u_q e_b >= thr0[q] / qscale_q with u_q = B(q) / qscale_q.  The pre-test uses U = max_q u_q
+    // (one fused multiply-add, more permissive: sound), the per-value test the query's own u_q.
+    // SAMPLE: rscale[row] (per row; NaN past the count), no thresholds.
     static_assert(MODE == MODE_FILTER || MODE == MODE_SAMPLE, "filter and sample passes only");
+    constexpr bool STEPS3 = TS != 0;
+    constexpr bool kPair = TS == 2;
+    static_assert(TS >= 0 && TS <= 2 && !(kPair && (RES || CODD_I8_LAG)), "pair barriers: staged tile-structured program only");
     static_assert(NQB == 16 || NQB == 8, "256 or 128 queries");
     constexpr int kDmaPerSlice = NQB / 4;                 // this wave's 1 KiB chunks of a slice
     constexpr int kDmaPerIv = RES ? 0 : kDmaPerSlice;     // slice DMA per interval
@@ -185,6 +225,13 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             reinterpret_cast<unsigned short*>(lds_w)[2 * (((j >> 2) * 16 + c) * 4 + (j & 3)) + (qb & 1)] = (unsigned short)(__float_as_uint(pre) >> 16);
             lds_w[576 + tid] = __float_as_uint(th);
             lds_w[320 + tid] = __float_as_uint(qscale[tid]);
+            // u_q (0 for padding and zero queries: their scale is 0) and the workgroup's maximum of it, per wave here, folded
+            // behind the prologue's barrier
+            const float qs = qscale[tid];
+            const float u = qs > 0.0f ? qscale[768 + tid] / qs : 0.0f;
+            lds_w[1088 + tid] = __float_as_uint(u);
+            const float um = i8_wave_max(u);
+            if (lane == 0) lds_w[260 + wave] = __float_as_uint(um);
         }
         if (tid < kLists) lds_w[256 + tid] = 0u;
     } else {
@@ -199,6 +246,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     const int64_t step_bytes = 4096;                       // 4 pieces x 1 KiB: this wave's 32 rows x 128 elements
     const int64_t tile_bytes = (int64_t)8 * nsteps * step_bytes;
 
+    float u_max = 0.0f;  // FILTER: max over the batch of B(q) / qscale_q (uniform; set behind the prologue's barrier)
     i32x4 acc[2][NQB];
 #pragma unroll
     for (int rs = 0; rs < 2; ++rs)
@@ -225,6 +273,22 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         }
     };
 
+    // the same in pieces (pair program: one vector-memory operation at a time, between MFMA groups)
+    i32x4 a_rsrc = {0, 0, 0, 0};
+    auto load_a_begin = [&]() __attribute__((always_inline)) {
+#ifdef CODD_I8_EXP_SAMETILE
+        const char* base = reinterpret_cast<const char*>(shadow8) + ((int64_t)wave * nsteps + l_s) * step_bytes;
+#else
+        const char* base = reinterpret_cast<const char*>(shadow8) + (l_u * tile_stride) * tile_bytes + ((int64_t)wave * nsteps + l_s) * step_bytes;
+#endif
+        a_rsrc = i8_rsrc(base, 4096);
+    };
+    auto load_a_end = [&]() __attribute__((always_inline)) {
+        if (--l_left > 0) {
+            if (++l_s == nsteps) { l_s = 0; l_u += G; }
+        }
+    };
+
     // ---- query slices: L2 -> LDS by LDS-DMA, slice of step t in LDS slice t & 3, requested two intervals ahead ----
     // wave w moves the 1 KiB chunks 8j + w (j < kDmaPerIv) of a slice: 64 lanes x 16 bytes each, contiguous on both sides
     // (pieces are ordered [query block][K half]: the first 2 NQB chunks of a 256-query slice are query blocks 0..NQB-1)
@@ -236,6 +300,12 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         for (int j = 0; j < kDmaPerSlice; ++j) i8_dma_b128(dst + j * 8192, lane16, rsrc_q, soff + j * 8192);
         q_s = q_s + 1 == nsteps ? 0 : q_s + 1;
     };
+    auto stage_dma_piece = [&](int slot, int j, bool last) __attribute__((always_inline)) {
+        const int soff = q_s * kI8SliceBytes + wave * 1024;
+        const unsigned dst = lds0 + (unsigned)(slot * kSlotBytes + wave * 1024);
+        i8_dma_b128(dst + j * 8192, lane16, rsrc_q, soff + j * 8192);
+        if (last) q_s = q_s + 1 == nsteps ? 0 : q_s + 1;
+    };
 
     // ---- row scales of run-tile ordinal u (this workgroup's tile number `ord`) -> LDS buffer ord & 1, by DMA too ----
     // one 256-byte DMA per wave and interval: the scales of rows [r0, r0 + 64) of the tile, r0 = min(32 wave, 192) — the
@@ -245,6 +315,14 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     // threshold, so the epilogue needs no row < n test; tiles past the corpus (padding intervals) read zeros.
     const int lane4 = lane * 4;
     auto rs_dma = [&](int64_t u, int ord) __attribute__((always_inline)) {
+        if (MODE == MODE_FILTER && bmeta) {
+            // the tile's eight blocks' {scale, error norm}: dwords [2 w], [2 w + 1] of the buffer belong to wave w (one 256-byte DMA:
+            // 32 blocks from the tile's first one — the allocation has the head room; every wave writes the same bytes)
+            const int64_t blk0 = u * tile_stride * (kTileRows / 32);
+            const int64_t nblk = (n + 31) / 32;
+            i8_dma_b32(lds0 + (unsigned)(4 * kI8SliceBytes + kI8Words * 4 + ((ord & 1) * kI8RsStride) * 4), lane4,
+                       i8_rsrc(bmeta + (blk0 < nblk ? blk0 : 0), blk0 < nblk ? 256u : 0u), 0);
+        } else {
         const int64_t row0 = u * tile_stride * kTileRows;
         const int64_t bound = (n + kTileRows - 1) / kTileRows * kTileRows;
         const int64_t left = bound - row0;
@@ -252,6 +330,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         const int r0 = wave * 32 < 192 ? wave * 32 : 192;
         i8_dma_b32(lds0 + (unsigned)(4 * kI8SliceBytes + kI8Words * 4 + ((ord & 1) * kI8RsStride + r0) * 4), lane4,
                    i8_rsrc(rscale + (left > 0 ? row0 : 0), (unsigned)(rows_here * 4)), r0 * 4);
+        }
     };
 
     // ---- epilogues ----
@@ -265,6 +344,9 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         unsigned par;              // which half of the double-buffered shared state the tile writes (uniform)
         unsigned wrow0;            // first row of the wave's 32-row block (uniform)
         float rsl;                 // its scale (uniform; NaN: the whole block lies past the count — every comparison fails)
+        float inv_rsl;             // 1 / rsl (uniform)
+        float eb;                  // the block's quantisation error norm (uniform)
+        float ueb;                 // U * eb: what the pre-test adds to acc * rsl (uniform)
         u32x4 thw[NQB / 8];        // the lane's NQB pre-test thresholds, two bf16 per word (see the kernel's set-up)
     };
     auto epi_begin = [&](int64_t cu, int ord, bool valid) __attribute__((always_inline)) {
@@ -280,8 +362,11 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         // ONE scale per 32-row block (shadow8_from_rows_kernel), so the wave's rows share it and the pre-test on a pair's
         // largest accumulator is EXACT at pair level: it passes iff some value of the pair passes.  Rows past the count
         // carry NaN: the block's first row exists whenever any of its rows does, and the per-value test masks the others.
-        const float rs0 = lds_rs[(ord & 1) * kI8RsStride + wave * 32];
+        const float rs0 = lds_rs[(ord & 1) * kI8RsStride + (bmeta ? 2 * wave : 32 * wave)], eb0 = bmeta ? lds_rs[(ord & 1) * kI8RsStride + 2 * wave + 1] : 0.0f;
         e.rsl = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(valid ? rs0 : __builtin_nanf(""))));
+        e.inv_rsl = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(1.0f / (valid ? rs0 : __builtin_nanf("")))));
+        e.eb = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(eb0))) * eb_scale;  // (eb_scale 0: the device-wide bound, thr = L - eps(q))
+        e.ueb = e.eb * u_max;
 #pragma unroll
         for (int j = 0; j < NQB / 8; ++j) e.thw[j] = *reinterpret_cast<const u32x4*>(lds_w + (j * 16 + c) * 4);
         return e;
@@ -296,13 +381,13 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         // is tightest); the per-value test below uses the exact one.
         const unsigned w = e.thw[qb >> 3][(qb >> 1) & 3];
         const float thp = __uint_as_float((qb & 1) ? (w & 0xffff0000u) : (w << 16));
-        if (__builtin_expect(__any((float)m * e.rsl >= thp), 0)) {
+        if (__builtin_expect(__any(__builtin_fmaf((float)m, e.rsl, e.ueb) >= thp), 0)) {
             int l = lane;
             asm volatile("" : "+v"(l));  // (lane coordinates derived BEHIND the opaque asm: hipcc otherwise computes them once at kernel start and parks them in scratch)
             const int c = l & 15, lg = l >> 4;
             const unsigned q = (unsigned)(qb * 16 + c);
             const unsigned row0 = e.wrow0 + (unsigned)(4 * lg);  // + 16 * rs + r
-            const float th = __uint_as_float(lds_w[576 + q]);    // the exact threshold (thr / qscale)
+            const float th = __uint_as_float(lds_w[576 + q]) - __uint_as_float(lds_w[1088 + q]) * e.eb;  // the query's exact threshold for this block (thr0 / qscale - u_q e_b)
             // Branches are what this path pays for (no prediction: every taken one refills the wave's instruction buffer,
             // every exec-mask test waits for the compare), so the common case — no lane holds more than one hit among
             // its 8 rows — runs straight-line: the per-value tests select the lane's hit and count them, one append.
@@ -325,23 +410,38 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                 }
 #endif
             };
-            float v[8], sv = 0.0f;
-            int si = -1, cnt = 0;
+            // The per-value test runs on the INTEGER accumulators against T, a lower bound of the smallest accumulator whose score
+            // (float)a * rsl reaches th: (int)(th / rsl) - 2 — two accumulator levels of slack (1/90,000 of a threshold each on the
+            // bench corpus) over the rounding of the division, so no hit of the float expression is lost and next to none is
+            // added (the hit list may hold extra rows, never miss one).  One compare per value instead of convert + multiply +
+            // compare: the eight waves of a workgroup are all in their epilogues at once, so its instruction count is wall time.
+            // NaN threshold (a zero query): nothing passes, as with the float compare.  Rows past the count: masked in the last tile.
+            const float x = th * e.inv_rsl;
+            int T = x >= 2.0e9f ? INT_MAX : (x <= -2.0e9f ? INT_MIN + 1 : (int)x - 2);
+            if (!(th == th)) T = INT_MAX;
+            int av[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) av[i] = i < 4 ? a0[i] : a1[i - 4];
+            if (e.wrow0 + 32u > n_rows) {  // (uniform: the corpus's last 32-row block only)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) av[i] = row0 + (unsigned)(16 * (i >> 2) + (i & 3)) < n_rows ? av[i] : INT_MIN;
+            }
+            int sa = 0, si = -1, cnt = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                v[i] = (float)(i < 4 ? a0[i] : a1[i - 4]) * e.rsl;  // the first-generation kernel's expression (its rscale[row] IS the block's scale)
-                const bool h = v[i] >= th && row0 + (unsigned)(16 * (i >> 2) + (i & 3)) < n_rows;
-                sv = h ? v[i] : sv;
+                const bool h = av[i] >= T;
+                sa = h ? av[i] : sa;
                 si = h ? i : si;
                 cnt += h ? 1 : 0;
             }
+            const float sv = (float)sa * e.rsl;  // the first-generation kernel's expression (its rscale[row] IS the block's scale)
 #ifdef CODD_I8_EXP_NOAPPEND
             asm volatile("" ::"v"(sv), "v"(si), "v"(cnt));  // diagnostic: the per-value test runs, nothing is appended
 #else
             if (__builtin_expect(__any(cnt > 1), 0)) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
-                    if (v[i] >= th && row0 + (unsigned)(16 * (i >> 2) + (i & 3)) < n_rows) append(v[i], i);
+                    if (av[i] >= T) append((float)av[i] * e.rsl, i);
             } else if (si >= 0) {
                 append(sv, si);
             }
@@ -426,7 +526,8 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     };
     // FUSED: the first K-step of a tile also carries the PREVIOUS tile's epilogue — pair qb is tested right in front of the
     // MFMAs that restart its accumulators from zero (K half 0, query block qb)
-    auto mfma_step = [&](auto SLOT, auto FIRST, auto FUSED, i32x4(&b)[kBD], unsigned qaddr, const EpiCtx* ectx) __attribute__((always_inline)) {
+    // vm(g): vector-memory operations the pair program issues BEHIND group g's MFMAs (see the interval loop), nothing otherwise
+    auto mfma_step = [&](auto SLOT, auto FIRST, auto FUSED, i32x4(&b)[kBD], unsigned qaddr, const EpiCtx* ectx, auto&& vm) __attribute__((always_inline)) {
         constexpr int slot = decltype(SLOT)::value;
         constexpr bool first = decltype(FIRST)::value;
         constexpr bool fused = decltype(FUSED)::value;
@@ -449,6 +550,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                 constexpr int g2 = g + kBD;
                 lds_read_b128_asm<(((g2 % NQB) * 2) + (g2 / NQB)) * 1024>(b[g % kBD], qaddr);
             }
+            vm(G_);
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -475,7 +577,18 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         load_a(ring[0]);
         if (LAG == 0) load_a(ring[1]);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // slices 0, 1, the first scales and corpus steps have landed
+        if (MODE == MODE_FILTER) {
+            const float um = fmaxf(fmaxf(__uint_as_float(lds_w[260]), __uint_as_float(lds_w[261])), fmaxf(__uint_as_float(lds_w[262]), __uint_as_float(lds_w[263])));
+            u_max = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(um)));
+        }
 
+#ifdef CODD_I8_EXP_STAMPS
+        // diagnostic build (guide: in-kernel stamps): per wave, shader cycles spent per phase, summed over its intervals.  s_memtime
+        // returns through the scalar cache, so each stamp drains lgkmcnt: placed where the LDS queue is empty anyway, except the
+        // one behind the corpus wait (4 fragment reads in flight there: the first MFMA group waits for the first of them anyway)
+        unsigned long long st_pre = 0, st_vm = 0, st_mfma = 0, st_sync = 0, st_epi = 0, st_iv = 0;
+        const unsigned long long st_begin = __builtin_readcyclecounter();
+#endif
         int64_t c_u = first_u;   // compute cursor (this wave's step s = t - LAG)
         int c_s = 0, c_ord = 0;
         int64_t w_u = first_u;   // workgroup cursor (step t)
@@ -492,7 +605,10 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         // BOOK: the interval may be a tile's second one (w_s == 1), behind whose barrier the workgroup's bookkeeping runs (hit-list
         // flush, sample keys): the tile-structured program knows statically which of its unrolled intervals that is, and the
         // flush code — 2 KB, with a handful of loop-invariant registers hipcc hoists out of the loop — exists once instead of six times
-        auto interval = [&](auto IU, auto EPI, auto FIRST, auto FUSED, auto BOOK, int t, const EpiCtx* ectx) __attribute__((always_inline)) {
+        // SYNC: 0 = a barrier behind every interval (the resident program: behind a tile's second interval only); pair program:
+        // 1 = nothing behind this (even) interval, 2 = behind this (odd) one every DMA this wave has issued has landed, barrier.
+        auto interval = [&](auto IU, auto EPI, auto FIRST, auto FUSED, auto BOOK, auto SYNC, int t, const EpiCtx* ectx) __attribute__((always_inline)) {
+            constexpr int sync = decltype(SYNC)::value;
             constexpr int iu = decltype(IU)::value;
             constexpr int ci = (iu + 3 - LAG) % 3, li = (ci + 2) % 3;
             if (decltype(EPI)::value && pending) {
@@ -500,8 +616,61 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                 pending = false;
             }
             __builtin_amdgcn_sched_barrier(0);
+#ifdef CODD_I8_EXP_STAMPS
+            const unsigned long long T0 = __builtin_readcyclecounter();
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             const unsigned qaddr = lds0 + (unsigned)((RES ? c_s : ((t - LAG) & 3)) * kSlotBytes + lane16);
             i32x4 b[kBD];
+#ifdef CODD_I8_EXP_STAMPS
+            unsigned long long T1 = 0, T2 = 0;
+#endif
+            if constexpr (sync != 0 && CODD_I8_SPREAD_VM) {
+                // Pair program: the interval's vector-memory operations go out one at a time BEHIND MFMA groups instead of in a block
+                // in front of them.  All eight waves reach an interval together, and a CU's address path takes one 1-KiB
+                // wave-instruction per ~16 cycles: the block cost every wave 500-900 cycles per K-step with the matrix pipe idle
+                // (profiles/r3/i8_tile_stamps.txt: 17 % of the launch).  Issue order (what the counted waits rely on):
+                //   even interval t: 4 corpus loads (step t + 2), scale DMA, the slices of steps t + 2 AND t + 3 (2 kDmaPerSlice DMA);
+                //   odd interval: 4 corpus loads, scale DMA.  Operation i goes behind group i * kStride.
+                // Younger than the corpus loads of interval t - 2 at the top of interval t: the rest of t - 2 and all of t - 1
+                //   = (1 + 2 kDmaPerSlice) + 5 (t even) = 1 + (5 + 2 kDmaPerSlice) (t odd);
+                // younger than the slice DMA of even interval t - 1 at the barrier behind odd interval t: t's five operations.
+                constexpr bool even = sync == 1;
+                constexpr int kStride = (2 * NQB) / 16;
+                constexpr int kOpsHere = 5 + (even ? 2 * kDmaPerSlice : 0);
+                static_assert((kOpsHere - 1) * kStride + 1 < 2 * NQB, "every operation has its group");
+                i8_wait_vm<6 + 2 * kDmaPerSlice>(ring[ci][0], ring[ci][1], ring[ci][2], ring[ci][3]);
+                __builtin_amdgcn_sched_barrier(0);
+                frag_prefetch(b, qaddr);
+#ifdef CODD_I8_EXP_STAMPS
+                __builtin_amdgcn_sched_barrier(0);
+                T1 = T2 = __builtin_readcyclecounter();
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                mfma_step(std::integral_constant<int, ci>{}, FIRST, FUSED, b, qaddr, ectx, [&](auto G_) __attribute__((always_inline)) {
+                    constexpr int g = decltype(G_)::value;
+                    // SIMD partners (waves w and w + 4) take turns: a 1-KiB vector-memory instruction holds its wave's issue for ~60
+                    // cycles, which the partner's MFMAs cover only if the partner is not issuing one of its own at the same moment:
+                    // waves 0..3 issue behind the even groups, waves 4..7 behind the odd ones (CODD_I8_SPREAD_VM == 2)
+                    constexpr int phase = (CODD_I8_SPREAD_VM == 2 && kStride == 2) ? g % kStride : 0;
+                    if constexpr ((g - phase) % kStride == 0 && (g - phase) / kStride < kOpsHere) {
+                        if (CODD_I8_SPREAD_VM == 2 && kStride == 2 && (wave >= 4) != (phase == 1)) return;
+                        constexpr int i = (g - phase) / kStride;
+                        if constexpr (i == 0) load_a_begin();
+                        if constexpr (i == 0) i8_load_b128_nt<0>(ring[li][0], lane16, a_rsrc);
+                        if constexpr (i == 1) i8_load_b128_nt<1024>(ring[li][1], lane16, a_rsrc);
+                        if constexpr (i == 2) i8_load_b128_nt<2048>(ring[li][2], lane16, a_rsrc);
+                        if constexpr (i == 3) { i8_load_b128_nt<3072>(ring[li][3], lane16, a_rsrc); load_a_end(); }
+                        if constexpr (i == 4) rs_dma(w_u, w_ord);
+#ifndef CODD_I8_EXP_NODMA
+                        if constexpr (i >= 5) {
+                            constexpr int d = i - 5, which = d / kDmaPerSlice, j = d % kDmaPerSlice;
+                            stage_dma_piece((t + 2 + which) & 3, j, j == kDmaPerSlice - 1);
+                        }
+#endif
+                    }
+                });
+            } else {
             if (CODD_I8_EARLY_FRAGS) frag_prefetch(b, qaddr);
             __builtin_amdgcn_sched_barrier(0);
             rs_dma(w_u, w_ord);
@@ -509,10 +678,25 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             if constexpr (!RES) stage_dma((t + 2) & 3);
 #endif
             load_a(ring[li]);
+#ifdef CODD_I8_EXP_STAMPS
+            __builtin_amdgcn_sched_barrier(0);
+            T1 = __builtin_readcyclecounter();
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             i8_wait_vm<2 * kOpsPerIv>(ring[ci][0], ring[ci][1], ring[ci][2], ring[ci][3]);
             __builtin_amdgcn_sched_barrier(0);
+#ifdef CODD_I8_EXP_STAMPS
+            T2 = __builtin_readcyclecounter();
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             if (!CODD_I8_EARLY_FRAGS) frag_prefetch(b, qaddr);
-            mfma_step(std::integral_constant<int, ci>{}, FIRST, FUSED, b, qaddr, ectx);
+            mfma_step(std::integral_constant<int, ci>{}, FIRST, FUSED, b, qaddr, ectx, [](auto) {});
+            }
+#ifdef CODD_I8_EXP_STAMPS
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long T3 = __builtin_readcyclecounter();
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             const int s = t - LAG;
             if (s >= 0) {
                 if (s < T && c_s == nsteps - 1) { pending = true; p_u = c_u; p_ord = c_ord; }
@@ -523,8 +707,23 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
 #else
             // (the resident program: one barrier per tile, in its second interval — slices are read-only, corpus fragments
             // and row scales belong to the wave, the hit lists / sample keys are double-buffered by tile parity)
-            if (RES && w_s != 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kAPerIv + kOpsPerIv) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kAPerIv + kOpsPerIv) : "memory");
+            if constexpr (sync == 2) {
+                // the slices of steps t + 1 (requested one interval ago) and t + 2 (requested in this one) have landed; younger
+                // than this interval's slice DMA are only its corpus loads
+                // (spread issue: the odd interval's own five operations — corpus loads, scale DMA — are what is younger than the
+                // even interval's slice DMA)
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(CODD_I8_SPREAD_VM ? 5 : kAPerIv) : "memory");
+            } else if constexpr (sync == 0) {
+                if (RES && w_s != 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(kAPerIv + kOpsPerIv) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kAPerIv + kOpsPerIv) : "memory");
+            }
+#endif
+#ifdef CODD_I8_EXP_STAMPS
+            {
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long T4 = __builtin_readcyclecounter();
+                st_pre += T1 - T0; st_vm += T2 - T1; st_mfma += T3 - T2; st_sync += T4 - T3; st_iv += 1;
+            }
 #endif
             // every wave has folded tile w_ord - 1 when the barrier of the interval with w_s == 1 releases, and no wave
             // writes that tile's half of the shared state again before the barrier inside the next tile (staged program:
@@ -570,33 +769,76 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                     ectx = epi_begin(pending ? p_u : c_u, pending ? p_ord : 0, pending);
                     pending = false;
                 } else if (pending) {
+#ifdef CODD_I8_EXP_STAMPS
+                    const unsigned long long E0 = __builtin_readcyclecounter();
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
                     epilogue(p_u, p_ord);
                     pending = false;
+#ifdef CODD_I8_EXP_STAMPS
+                    __builtin_amdgcn_sched_barrier(0);
+                    st_epi += __builtin_readcyclecounter() - E0;
+#endif
                 }
                 // the tile's first K-step starts its accumulators from zero: no clearing pass in the epilogue
-                interval(std::integral_constant<int, 0>{}, no, std::true_type{}, fuse, no, t, &ectx);
-                interval(std::integral_constant<int, 1>{}, no, no, no, std::true_type{}, t + 1, nullptr);   // (w_s == 1: the bookkeeping)
-                interval(std::integral_constant<int, 2>{}, no, no, no, no, t + 2, nullptr);
-                t += 3;
-                for (int s3 = 3; s3 < nsteps; s3 += 3) {
-                    interval(std::integral_constant<int, 0>{}, no, no, no, no, t, nullptr);
-                    interval(std::integral_constant<int, 1>{}, no, no, no, no, t + 1, nullptr);
-                    interval(std::integral_constant<int, 2>{}, no, no, no, no, t + 2, nullptr);
+                const std::true_type yes{};
+                const std::integral_constant<int, 0> i0{};
+                const std::integral_constant<int, 1> i1{};
+                const std::integral_constant<int, 2> i2{};
+                if constexpr (kPair) {
+                    // intervals 0..nsteps-1 of a tile: the odd ones end in the barrier (nsteps is a multiple of 6, so every tile
+                    // starts on an even interval)
+                    interval(i0, no, yes, fuse, no, i1, t, &ectx);
+                    interval(i1, no, no, no, yes, i2, t + 1, nullptr);   // (w_s == 1: the bookkeeping, behind the barrier)
+                    interval(i2, no, no, no, no, i1, t + 2, nullptr);
                     t += 3;
+                    for (int s3 = 3; s3 < nsteps; s3 += 6) {
+                        interval(i0, no, no, no, no, i2, t, nullptr);
+                        interval(i1, no, no, no, no, i1, t + 1, nullptr);
+                        interval(i2, no, no, no, no, i2, t + 2, nullptr);
+                        t += 3;
+                        if (s3 + 3 < nsteps) {
+                            interval(i0, no, no, no, no, i1, t, nullptr);
+                            interval(i1, no, no, no, no, i2, t + 1, nullptr);
+                            interval(i2, no, no, no, no, i1, t + 2, nullptr);
+                            t += 3;
+                        }
+                    }
+                } else {
+                    interval(i0, no, yes, fuse, no, i0, t, &ectx);
+                    interval(i1, no, no, no, yes, i0, t + 1, nullptr);   // (w_s == 1: the bookkeeping)
+                    interval(i2, no, no, no, no, i0, t + 2, nullptr);
+                    t += 3;
+                    for (int s3 = 3; s3 < nsteps; s3 += 3) {
+                        interval(i0, no, no, no, no, i0, t, nullptr);
+                        interval(i1, no, no, no, no, i0, t + 1, nullptr);
+                        interval(i2, no, no, no, no, i0, t + 2, nullptr);
+                        t += 3;
+                    }
                 }
             }
         } else {
             const std::false_type no{};
             for (int t0 = 0; t0 < TI; t0 += 3) {
-                interval(std::integral_constant<int, 0>{}, std::true_type{}, no, no, std::true_type{}, t0, nullptr);
-                interval(std::integral_constant<int, 1>{}, std::true_type{}, no, no, std::true_type{}, t0 + 1, nullptr);
-                interval(std::integral_constant<int, 2>{}, std::true_type{}, no, no, std::true_type{}, t0 + 2, nullptr);
+                const std::integral_constant<int, 0> s0{};
+                interval(std::integral_constant<int, 0>{}, std::true_type{}, no, no, std::true_type{}, s0, t0, nullptr);
+                interval(std::integral_constant<int, 1>{}, std::true_type{}, no, no, std::true_type{}, s0, t0 + 1, nullptr);
+                interval(std::integral_constant<int, 2>{}, std::true_type{}, no, no, std::true_type{}, s0, t0 + 2, nullptr);
             }
         }
         // The corpus loads of the last two intervals are never consumed: hipcc considers their destination registers free
         // from here on and hands them to the code below, while the loads are still in flight and will overwrite them.
         // Nothing of this wave may be in flight past this point.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef CODD_I8_EXP_STAMPS
+        if (MODE == MODE_FILTER && bucket_key && lane == 0) {
+            // (bucket_key is unused by the filter pass: the stamps build's host passes a scratch buffer there; read back with
+            // codd_knn_exp_read_stamps)
+            unsigned long long* d = reinterpret_cast<unsigned long long*>(bucket_key) + ((int64_t)blockIdx.x * 8 + wave) * 8;
+            d[0] = st_pre; d[1] = st_vm; d[2] = st_mfma; d[3] = st_sync; d[4] = st_epi; d[5] = st_iv;
+            d[6] = __builtin_readcyclecounter() - st_begin; d[7] = (unsigned long long)my_tiles;
+        }
+#endif
         if (pending) epilogue(p_u, p_ord);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (MODE == MODE_SAMPLE && pub_ord < my_tiles && tid < 256) {

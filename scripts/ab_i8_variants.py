@@ -13,8 +13,10 @@ VARIANTS = {
     "noappend": {"CODD_I8_EXP_NOAPPEND": 1},
     "noflush": {"CODD_I8_EXP_NOFLUSH": 1},
     "noglobal": {"CODD_I8_EXP_NOGLOBAL": 1},
-    "latefrags": {"CODD_I8_EARLY_FRAGS": 0, "CODD_EXPERIMENTS": 1},
-    "nofuse": {"CODD_I8_FUSE_EPI": 0},  # round 3: the epilogue as a block of its own between tiles (round 2's placement)
+    "latefrags": {"CODD_I8_EARLY_FRAGS": 0},
+    "fuse": {"CODD_I8_FUSE_EPI": 1},        # round 3: tile i's pair tests inside the first K-step of tile i + 1 (measured 1.7-3 % slower)
+    "spread1": {"CODD_I8_SPREAD_VM": 1},    # round 3: the pair program's vector-memory operations one at a time behind MFMA groups
+    "spread2": {"CODD_I8_SPREAD_VM": 2},    # ... SIMD partners taking turns
 }
 
 
@@ -27,7 +29,9 @@ if sys.argv[1] == "build":
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(3) as ex:
         # the *_EXP_* switches break results on purpose: they only compile in experiment builds
-        list(ex.map(lambda kv: b.build_variant(kv[0], {**kv[1], **({'CODD_EXPERIMENTS': 1} if any('_EXP_' in k for k in kv[1]) else {})}), VARIANTS.items()))
+        # every schedule switch is experiment-only (#error otherwise): only the shipped defaults are under test
+        only = sys.argv[2:]
+        list(ex.map(lambda kv: b.build_variant(kv[0], {**kv[1], 'CODD_EXPERIMENTS': 1}), [kv for kv in VARIANTS.items() if not only or kv[0] in only]))
     print("built", list(VARIANTS))
 else:
     rows = sys.argv[2] if len(sys.argv) > 2 else "4000000"

@@ -5,7 +5,7 @@ coarse-IVF + exact scores against this engine's own flat search on the same shar
     python scripts/bench_ivf.py [--rows 12500000 --dim 1024 --nlist 2048 --nprobe 8]
 
 Prints one JSON object: build time, list statistics, recall@10 (IVF vs exact flat), p50 latency and
-queries/s of both at B = 1 and B = 32.  Clustered synthetic data (SURVEY.md §8d row 5 in spirit).
+queries/s of both at B = 1, 32 and 256.  Clustered synthetic data (SURVEY.md §8d row 5 in spirit).
 """
 import argparse
 import json
@@ -76,7 +76,7 @@ def main():
         p50 = statistics.median(lat)
         return {"p50_ms": p50, "qps": B / p50 * 1e3}
 
-    for B in (1, 32):
+    for B in (1, 32, 256):
         out[f"ivf_B{B}"] = timed(lambda qq: ivf.search_ivf(ix, qq, k, a.nprobe), B)
         out[f"flat_B{B}"] = timed(lambda qq: ix.search_tensors(qq, k), B)
     elem = 4 if a.dtype == "f32" else 2

@@ -41,3 +41,30 @@ def test_sharded_code_path_line():
     line = run_bench("--force-dist", "--no-cpu-baseline", "--rows", "400000")
     assert line["results_valid"] is True and line["config"]["batches_in_flight"] == 2
     assert line["roofline"]["events_from"].startswith("the same K steps")
+
+
+def test_driver_command_shape_under_torch_distributed_run():
+    """the exact command shape the driver uses for N > 1 — `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` — exercised end to end with N = 1 on the
+    one-GPU box: the launcher starts as a fresh child process (before anything in THIS process has touched the GPU for it),
+    rank 0 initialises RCCL from the RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* it is handed, takes the sharded code path
+    (--force-dist: one all_gather of B*k keys per step, two batches in flight) and prints exactly one line."""
+    import socket
+
+    with socket.socket() as s:   # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for key in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(key, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--rows", "400000", "--steps", "4", "--warmup", "1", "--latency-iters", "3",
+           "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["steps"] == 4 and line["results_valid"] is True and line["value"] > 0
+    assert line["config"]["batches_in_flight"] == 2 and line["config"]["rows_per_gpu"] == 400000
+    assert line["roofline"]["achieved"] > 0 and "rehearsal" not in line

@@ -160,6 +160,35 @@ def test_overflow_falls_back_and_stays_exact(Index):
     ix.close()
 
 
+@pytest.mark.parametrize("B,d,dtype,fuse", [(200, 768, "f32", 1), (200, 768, "f32", 0), (96, 256, "bf16", 1), (130, 1024, "f16", 1)])
+def test_overflow_in_a_large_batch_is_answered_inside_the_finalize_launch(Index, B, d, dtype, fuse):
+    """Round 3: for batches above 64 queries finalize and the exact-scan fallback are ONE launch (finalize_fb_kernel: its scan
+    workgroups derive the queue from the hit counters).  Same overflow as above — 5,000 near-copies, candidate lists shrunk to
+    64 — on the int8 tile kernel's and the first-generation kernels' batch sizes and on 2-byte rows; "fuse_fallback" = 0 is
+    the two-launch form.  Affected queries only; same bits as the oracle; repeated searches reuse the arrival ticket."""
+    rng = np.random.default_rng(B + d)
+    n, k = 40_000, 10
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    centre = rng.standard_normal(d).astype(np.float32)
+    dup = rng.choice(n, size=5000, replace=False)
+    raw[dup] = centre + 1e-3 * rng.standard_normal((5000, d)).astype(np.float32)
+    q = rng.standard_normal((B, d)).astype(np.float32)
+    hot = [3, 11, 77, B - 1]
+    for h in hot:
+        q[h] = centre + 1e-3 * rng.standard_normal(d).astype(np.float32)
+    ix = build(Index, raw, dtype)
+    ix.set_option("shadow8", 1 if dtype == "f32" else 0)   # (f32 cases: the int8 tile kernel's pass; 2-byte rows: the fp16 filter's)
+    ix.set_option("hit_cap", 1024 if dtype == "f32" else 64)   # (the int8 slack leaves an ordinary query ~150 candidates here, the fp16 one a dozen)
+    ix.set_option("fuse_fallback", fuse)
+    ix.set_option("shadow8_cooldown", 0)
+    d_ref, i_ref = oracle_answer(raw, q, k, dtype)
+    for rep in range(2):
+        dist, rows = ix.search(q, k)
+        assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref), rep
+        assert ix.stat("fallback_queries") == (rep + 1) * len(hot)
+    ix.close()
+
+
 def test_workgroup_hit_list_overflow_goes_straight_to_the_global_lists(Index):
     """One tile holds 256 near-copies of a vector and 24 queries point at it: 6,144 hits land in one workgroup's
     2,048-entry LDS list inside a single tile.  Round 1 poisoned the affected queries' counters and sent them to the
@@ -191,10 +220,13 @@ def test_forty_thousand_near_copies_first_generation_kernels(Index, shadow8, B):
     centre = rng.standard_normal(d).astype(np.float32)
     centre /= np.linalg.norm(centre)
     members = rng.choice(n, size=42_000, replace=False)
-    raw[members] = centre + 0.1 * rng.standard_normal((42_000, d)).astype(np.float32) / np.sqrt(d)
+    # (spread of the cluster: inside the slack of the filter under test — the 2-byte shadow is fp16 since round 3, eps 0.0011
+    # at 768-d, seven times tighter than bf16's: the same cluster needs a fifth of the noise to stay inseparable)
+    noise = 0.1 if shadow8 else 0.02
+    raw[members] = centre + noise * rng.standard_normal((42_000, d)).astype(np.float32) / np.sqrt(d)
     q = rng.standard_normal((B, d)).astype(np.float32)
     hot = B * 3 // 4
-    q[:hot] = centre + 0.1 * rng.standard_normal((hot, d)).astype(np.float32) / np.sqrt(d)
+    q[:hot] = centre + noise * rng.standard_normal((hot, d)).astype(np.float32) / np.sqrt(d)
     ix = build(Index, raw)
     ix.set_option("shadow8", shadow8)
     dist, rows = ix.search(q, k)

@@ -72,8 +72,10 @@ def test_tile_kernel_is_exact(Index, n, d, B, k, dtype, i8v2):
 
 
 def test_tile_kernel_writes_the_same_candidate_lists_as_the_first_generation(Index):
-    """Same thresholds, same per-row test: the number of candidates and of survivors per pass must not depend on which
-    kernel ran (the integer pre-test may only skip pairs that hold no hit)."""
+    """Same sample, same anchors: the results must not depend on which kernel ran.  Since round 3 the tile kernel evaluates the
+    int8 bound per 32-row block (each block's own quantisation error norm instead of the corpus's worst), so its candidate list
+    is a SUBSET-sized one: fewer candidates than the first-generation kernel's (device-wide bound), never more than a
+    hair above it (its integer per-value test has two accumulator levels of slack); `per_block` = 0 gives the old lists back."""
     rng = np.random.default_rng(77)
     n, d, B, k = 120_000, 768, 256, 10
     raw = rng.standard_normal((n, d)).astype(np.float32)
@@ -85,8 +87,16 @@ def test_tile_kernel_writes_the_same_candidate_lists_as_the_first_generation(Ind
         assert ix.stat("i8v2_passes") == v
         stats.append((ix.stat("filter_hits"), ix.stat("filter_survivors"), dist.copy(), rows.copy()))
         ix.close()
-    assert stats[0][0] == stats[1][0] and stats[0][1] == stats[1][1]
+    assert stats[0][0] * 0.4 <= stats[1][0] <= stats[0][0] * 1.01 + 8, (stats[0][0], stats[1][0])
+    assert stats[1][1] <= stats[0][1] * 1.01 + 8, (stats[0][1], stats[1][1])
     assert np.array_equal(stats[0][2], stats[1][2]) and np.array_equal(stats[0][3], stats[1][3])
+    # the device-wide bound in both kernels: the tile kernel's list holds the first-generation kernel's, plus a hair
+    ix = build(Index, raw, "f32", 1)
+    ix.set_option("per_block", 0)
+    dist, rows = ix.search(q, k)
+    assert stats[0][0] <= ix.stat("filter_hits") <= stats[0][0] * 1.01 + 8
+    assert np.array_equal(dist, stats[0][2]) and np.array_equal(rows, stats[0][3])
+    ix.close()
 
 
 def test_tile_kernel_negative_and_zero_thresholds_and_zero_queries(Index):

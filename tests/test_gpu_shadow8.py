@@ -27,6 +27,7 @@ def build8(Index, raw, dtype="f32"):
         ix.set_option(key, 1)
     ix.set_option("shadow8", 1)
     ix.set_option("shadow8_max_batch", 32)
+    ix.set_option("small_batch_max", 0)   # (these tests are about the filter chain; the single-launch kernel has tests/test_gpu_small_batch.py)
     return ix
 
 
@@ -290,4 +291,57 @@ def test_six_step_rows_with_two_resident_slices_are_exact(Index):
         ix.set_option("resident_q", 1)
         assert np.array_equal(rows2, rows) and np.array_equal(dist2, dist)
     assert ix.stat("fallback_queries") == 0
+    ix.close()
+
+
+def test_one_badly_quantising_row_no_longer_widens_every_query(Index):
+    """the int8 bound's row-error term was ONE device-wide running maximum — a single badly quantising row
+    widened every query's slack (or, above 0.04, sent the whole index to the slower 2-byte filter) for the life of the index,
+    even after the row was overwritten.  Round 3: i8_tile_kernel and finalize evaluate the bound per 32-row block, the
+    device-wide figure is re-derived from the blocks after every build, and a few wide blocks do not switch the filter off."""
+    import torch
+
+    rng = np.random.default_rng(21)
+    n, d, B, k = 90_000, 768, 256, 10
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((B, d)).astype(np.float32)
+
+    def fresh(rows):
+        ix = Index(d)
+        ix.upsert(np.arange(rows.shape[0], dtype=np.int64), rows)
+        for key in ("filter_min_rows", "filter_min_rows_small", "filter_min_batch"):
+            ix.set_option(key, 1)
+        return ix
+
+    ix = fresh(raw)
+    ix.search(q, k)
+    base_hits = ix.stat("filter_hits")
+    base_eps = ix.stat("shadow8_eps_r_micro")
+    assert 0 < base_eps < 40_000 and ix.stat("i8v2_passes") == 1
+    ix.close()
+
+    bad = raw.copy()
+    bad[[5, 40_000, 77_777], 0] = 300.0     # three rows of one large element and many tiny ones: int8 rounds the tiny ones away
+    ix = fresh(bad)
+    d_ref, i_ref = o.search(o.normalize_rows(bad), "f32", o.normalize_rows(q), k)
+    dist, rows = ix.search(q, k)             # (first search: the error norms have not been read back yet)
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    torch.cuda.synchronize()
+    assert ix.stat("shadow8_eps_r_micro") > 40_000 and ix.stat("shadow8_wide_blocks") == 3
+    passes8 = ix.stat("shadow8_passes")
+    h0 = ix.stat("filter_hits")
+    dist, rows = ix.search(q, k)
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    assert ix.stat("shadow8_passes") == passes8 + 1, "three wide blocks in 2,800 must not switch the int8 filter off for this batch size"
+    # the three wide blocks contribute at most their own rows as extra candidates (3 x 32 per query); nobody else's slack moved
+    assert ix.stat("filter_hits") - h0 <= base_hits * 1.02 + 3 * 32 * B
+    # the rows are overwritten with ordinary ones: the device-wide figure comes back down (it used to stay up for ever)
+    ix.upsert(np.array([5, 40_000, 77_777], dtype=np.int64), raw[[5, 40_000, 77_777]])
+    ix.search(q, k)
+    torch.cuda.synchronize()
+    ix.search(q[:8].copy(), k)               # (the read-back is looked at by the next search)
+    assert ix.stat("shadow8_eps_r_micro") < 40_000 and ix.stat("shadow8_wide_blocks") == 0
+    d2, r2 = ix.search(q, k)
+    d_ref2, i_ref2 = o.search(o.normalize_rows(raw), "f32", o.normalize_rows(q), k)
+    assert np.array_equal(r2, i_ref2) and np.array_equal(d2, d_ref2)
     ix.close()

@@ -29,7 +29,7 @@ def test_hot_kernels_do_not_spill():
     # the second-generation int8 kernel (filter_i8.h): two waves per SIMD and no scratch (a reload inside the loop would wait
     # vmcnt(0) and drain the hand-counted prefetch)
     tile = [name for name in rows if "i8_tile_kernel" in name]
-    assert len(tile) == 12, report  # filter (3-step-multiple rows / others) and sample, for 16 and for 8 query blocks, staged and resident slices
+    assert len(tile) == 14, report  # filter (generic / 3-step-multiple / 6-step-multiple rows) and sample, for 16 and for 8 query blocks, staged and resident slices
     for name in tile:
         # NO instantiation may touch scratch: the kernel issues its corpus loads and LDS-DMA by inline asm that hipcc cannot see
         # as in flight, so a ring[] / b[] register spilled between its load and the counted s_waitcnt would store stale bytes —
@@ -39,3 +39,34 @@ def test_hot_kernels_do_not_spill():
     int8 = next(name for name in rows if "gemm_filter_kernel<0, 1, 1, 0>" in name)  # the single-query latency kernel (int8 shadow)
     assert rows[int8]["occ"] >= 2, report
     assert rows[full]["vgpr"] <= 256 and rows[full]["occ"] == 2, report
+
+
+def test_hand_issued_vector_memory_operations_carry_their_own_wait_states():
+    """gfx9 hazard: 5 wait states between a VALU write of an SGPR (v_readfirstlane / v_readlane — hipcc's SGPR-spill reloads)
+    and a vector-memory instruction reading it.  hipcc pads its own instructions, not the inside of inline asm; in round 3 a
+    descriptor word reloaded right in front of a hand-issued load was read stale (non-deterministic lost neighbours).  Every
+    inline-asm buffer_load of i8_tile_kernel must therefore sit behind >= 5 wait states INSIDE its own asm block."""
+    import os
+    import tempfile
+
+    src = b.os.path.join(b._ROOT, "scripts", "dev", "one_kernel.hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "k.s")
+        cmd = [b._hipcc(), *[f for f in b.HIPCC_FLAGS if f not in ("-shared", "-fPIC")], "--cuda-device-only", "-S", "-I", b.os.path.join(b._ROOT, "include"),
+               "-I", b.CSRC, "-DONEK_MODE=0", "-DONEK_S3=2", "-DONEK_NQB=16", "-DONEK_RES=false", "-o", out, src]
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+        assert proc.returncode == 0, proc.stderr[-2000:]
+        text = open(out).read()
+    blocks = re.findall(r";;#ASMSTART\n(.*?);;#ASMEND", text, flags=re.S)
+    loads = 0
+    for blk in blocks:
+        lines = [l.strip() for l in blk.strip().splitlines() if l.strip()]
+        for i, l in enumerate(lines):
+            if l.startswith("buffer_load"):
+                loads += 1
+                waits = 0
+                for prev in lines[:i]:
+                    m = re.match(r"s_nop (\d+)", prev)
+                    waits += int(m.group(1)) + 1 if m else 1
+                assert waits >= 5, f"hand-issued load without its wait states: {lines}"
+    assert loads >= 60, loads  # 13 per interval x 6 unrolled intervals, prologue, ...
