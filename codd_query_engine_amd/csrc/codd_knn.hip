@@ -955,6 +955,165 @@ __global__ __launch_bounds__(256) void ivf_scan_kernel(const void* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// IVF at batch (round 3): a probed list is scanned ONCE for all the queries of the batch that probe it.  ivf_scan_kernel reads a
+// list once per (query, list) pair — 256 queries x 32 probes over 2,048 lists read every list four times.  Here the pairs are
+// grouped by list on the device (count, prefix sums, scatter: three tiny launches), every work item is (list, up to kIvfNB
+// pairs): the list's rows enter registers once and are scored against the item's queries with the canonical exact expression.
+// The item writes each pair's top-k to the pair's own slot of the partial buffer, so the merge behind it is the same launch
+// as for the unshared scan and the results are the same bits.
+// ---------------------------------------------------------------------------------------------
+constexpr int kIvfNB = 4;  // queries per work item
+__global__ __launch_bounds__(256) void ivf_pair_count_kernel(const u64* __restrict__ probe_keys, int npairs, unsigned* __restrict__ cnt) {
+    const int p = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (p < npairs && probe_keys[p] != 0ull) atomicAdd(&cnt[key_row(probe_keys[p])], 1u);
+}
+// one workgroup: exclusive prefix sums over the lists — pair_start[l] (where list l's pairs go) and item_start[l] (its work
+// items: ceil(cnt / kIvfNB)); cnt[] is cleared on the way (the scatter reuses it as its fill counters); nitems at item_start[nlist]
+__global__ __launch_bounds__(1024) void ivf_pair_offsets_kernel(unsigned* __restrict__ cnt, int nlist, unsigned* __restrict__ pair_start,
+                                                                unsigned* __restrict__ item_start) {
+    __shared__ unsigned s_p[1024], s_i[1024];
+    const int tid = (int)threadIdx.x;
+    const int per = (nlist + 1023) / 1024;
+    unsigned sp = 0, si = 0;
+    for (int j = 0; j < per; ++j) {
+        const int l = tid * per + j;
+        const unsigned c = l < nlist ? cnt[l] : 0u;
+        sp += c;
+        si += (c + kIvfNB - 1) / kIvfNB;
+    }
+    s_p[tid] = sp;
+    s_i[tid] = si;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+        const unsigned a = tid >= off ? s_p[tid - off] : 0u, b = tid >= off ? s_i[tid - off] : 0u;
+        __syncthreads();
+        s_p[tid] += a;
+        s_i[tid] += b;
+        __syncthreads();
+    }
+    unsigned bp = s_p[tid] - sp, bi = s_i[tid] - si;   // exclusive bases of this thread's lists
+    for (int j = 0; j < per; ++j) {
+        const int l = tid * per + j;
+        if (l < nlist) {
+            const unsigned c = cnt[l];
+            pair_start[l] = bp;
+            item_start[l] = bi;
+            bp += c;
+            bi += (c + kIvfNB - 1) / kIvfNB;
+            cnt[l] = 0u;
+        }
+    }
+    if (tid == 1023) {
+        pair_start[nlist] = s_p[1023];
+        item_start[nlist] = s_i[1023];
+    }
+}
+__global__ __launch_bounds__(256) void ivf_pair_scatter_kernel(const u64* __restrict__ probe_keys, int npairs, const unsigned* __restrict__ pair_start,
+                                                               unsigned* __restrict__ fill, unsigned* __restrict__ sorted_pairs) {
+    const int p = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (p >= npairs || probe_keys[p] == 0ull) return;
+    const uint32_t l = key_row(probe_keys[p]);
+    sorted_pairs[pair_start[l] + atomicAdd(&fill[l], 1u)] = (unsigned)p;
+}
+// one work item per workgroup: item -> (list, its kIvfNB-pair group) by binary search in item_start
+template <int DT, int NITER, int SLOTS>
+__global__ __launch_bounds__(256) void ivf_scan_shared_kernel(const void* __restrict__ rows_, const uint32_t* __restrict__ ids, const int64_t* __restrict__ offsets,
+                                                              const unsigned* __restrict__ pair_start, const unsigned* __restrict__ item_start,
+                                                              const unsigned* __restrict__ sorted_pairs, int nlist, int nprobe, int dpad,
+                                                              const float* __restrict__ qn, int k, uint32_t row_base, u64* __restrict__ partial) {
+    typedef RowTraits<DT> RT;
+    constexpr int E = RT::E;
+    const unsigned item = blockIdx.x;
+    if (item >= item_start[nlist]) return;   // (the grid is sized for the worst case: one item per pair)
+    int lo_l = 0, hi_l = nlist;              // the last list whose item_start <= item
+    while (hi_l - lo_l > 1) {
+        const int mid = (lo_l + hi_l) >> 1;
+        if (item_start[mid] <= item) lo_l = mid; else hi_l = mid;
+    }
+    const int list = lo_l;
+    const unsigned g = item - item_start[list];
+    const unsigned p0 = pair_start[list] + g * kIvfNB, p1e = pair_start[list + 1];
+    const int nq = (int)((p1e - p0) < (unsigned)kIvfNB ? (p1e - p0) : (unsigned)kIvfNB);
+    const int lane = lane_id();
+    const int wave = (int)(threadIdx.x >> 6);
+    const int nchunks = dpad / E;
+    unsigned pair[kIvfNB];
+    float qf[kIvfNB][NITER][E];
+#pragma unroll
+    for (int b = 0; b < kIvfNB; ++b) {
+        pair[b] = b < nq ? sorted_pairs[p0 + b] : 0u;
+        const int64_t qi = (int64_t)(pair[b] / (unsigned)nprobe);
+#pragma unroll
+        for (int it = 0; it < NITER; ++it) {
+            const int j = lane + kWave * it;
+#pragma unroll
+            for (int e = 0; e < E; ++e) qf[b][it][e] = (b < nq && j < nchunks) ? qn[qi * dpad + (int64_t)j * E + e] : 0.0f;
+        }
+    }
+    WaveTopK<SLOTS> L[kIvfNB];
+#pragma unroll
+    for (int b = 0; b < kIvfNB; ++b) L[b].init();
+    const int64_t begin = offsets[list], end = offsets[list + 1];
+    const uint4* base = reinterpret_cast<const uint4*>(rows_);
+    for (int64_t g4 = begin + wave * 4; g4 < end; g4 += 16) {
+        float w[4][NITER][E];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = g4 + r < end ? g4 + r : end - 1;
+            const uint4* p = base + row * (int64_t)nchunks + lane;
+#pragma unroll
+            for (int it = 0; it < NITER; ++it) {
+                uint4 c = make_uint4(0u, 0u, 0u, 0u);
+                if (lane + kWave * it < nchunks) c = p[kWave * it];
+                RT::widen(c, w[r][it]);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < kIvfNB; ++b) {
+            float a[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int it = 0; it < NITER; ++it)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc = __builtin_fmaf(qf[b][it][e], w[r][it][e], acc);
+                a[r] = acc;
+            }
+            const float y = butterfly_sum4(a[0], a[1], a[2], a[3], lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(y), 16 * r));
+                if (g4 + r < end && b < nq) L[b].offer(make_key(sc, row_base + ids[g4 + r]), k, lane);
+            }
+        }
+    }
+    __shared__ u64 lds[4 * kIvfNB * SLOTS * kWave];
+#pragma unroll
+    for (int b = 0; b < kIvfNB; ++b)
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) lds[((wave * kIvfNB + b) * SLOTS + sl) * kWave + lane] = L[b].v[sl];
+    __syncthreads();
+    for (int b = wave; b < nq; b += 4) {
+        WaveTopK<SLOTS> M;
+        M.init();
+        for (int wv = 0; wv < 4; ++wv)
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                u64 cand = lds[((wv * kIvfNB + b) * SLOTS + sl) * kWave + lane];
+                if (sl * kWave + lane >= k) cand = 0ull;
+                M.offer_lanes(cand, k, lane);
+            }
+        u64* dst = partial + (int64_t)pair[b] * k;   // the pair's own slot: [query][probe rank][k]
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const int rank = sl * kWave + lane;
+            if (rank < k) dst[rank] = M.v[sl];
+        }
+    }
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -995,6 +1154,7 @@ struct WorkBufs {
     u64* sb_cand = nullptr;    int64_t sb_cand_cap = 0;    // small_batch_kernel: [waves][kSbKeep] published keys, then [waves] dropmax
     u64* probe_keys = nullptr; int64_t probe_cap = 0;      // IVF: [B][nprobe] coarse keys
     u64* ivf_partial = nullptr; int64_t ivf_partial_cap = 0;
+    unsigned* ivf_group = nullptr; int64_t ivf_group_cap = 0;  // IVF at batch: [nlist] counters, [nlist+1] pair starts, [nlist+1] item starts, [B*nprobe] pairs by list
 };
 constexpr int kMaxWork = 4;
 struct WorkSlot {
@@ -1061,6 +1221,7 @@ struct codd_knn_index : WorkBufs {
     int i8v2 = 2;                 // batches of 65..256 queries on rows of >= 384 elements (3 K-steps) take i8_tile_kernel (filter_i8.h); 1: only rows of
                                   // more than 512 elements (below, the first-generation kernel keeps the query block resident in LDS: 6-12 % slower); 0: never
     int i8v2_half = 1;            // ... and so do batches of 65..128 queries (its 8-query-block instantiation)
+    int ivf_share = 1;            // IVF search: from 1,024 (query, list) pairs on, a probed list is scanned once for all its queries ("ivf_share": 0 = per pair)
     int fuse_fallback = 1;        // batches above 64 queries, k <= 64: finalize and the exact-scan fallback in one launch ("fuse_fallback": 0 = two launches)
     int small_batch_max = 0;      // 1: a single query is answered in one launch by small_batch_kernel where it applies.  OFF by default: measured SLOWER than the
                                   // six-launch chain (1M x 768, B = 1: kernel 0.27 ms, p50 0.33 ms against 0.25 ms; profiles/r3/small_batch_latency.txt)
@@ -2251,7 +2412,7 @@ int codd_knn_destroy(codd_knn_index* ix) {
         if (b) (void)hipFree(b);
     for (WorkSlot& w : ix->slots) {
         void* wb[] = {w.bufs.qn, w.bufs.partial, w.bufs.keys_tmp, w.bufs.qfrag, w.bufs.thr, w.bufs.bucket_max, w.bufs.hits, w.bufs.ctl,
-                      w.bufs.fb_partial, w.bufs.probe_keys, w.bufs.ivf_partial, w.bufs.qfrag8, w.bufs.qmeta, w.bufs.sb_cand};
+                      w.bufs.fb_partial, w.bufs.probe_keys, w.bufs.ivf_partial, w.bufs.ivf_group, w.bufs.qfrag8, w.bufs.qmeta, w.bufs.sb_cand};
         for (void* b : wb)
             if (b) (void)hipFree(b);
         if (w.handover) (void)hipEventDestroy(w.handover);
@@ -2611,14 +2772,55 @@ int codd_knn_ivf_search(codd_knn_index* ix, const float* dev_queries, int B, int
     if ((rc = launch_normalize(DT_F32, dev_queries, B, ix->dim, ix->dpad, 1, nullptr, 0, ix->qn, nullptr, st)) != 0) return rc;
     // 1. coarse: the nprobe best lists per query (exact scan of the centroids, tiny)
     if ((rc = exact_scan(ix->coarse, ix->qn, B, nprobe, 0u, ix->probe_keys, nullptr, nullptr, st)) != 0) return rc;
+    const int nchunks = ix->dpad / elems_per_chunk(ix->dtype);
+    const int niter = (nchunks + kWave - 1) / kWave;
+    const int slots = k <= 64 ? 1 : 2;
+    // 2a. a batch with enough (query, list) pairs to fill the chip without splitting lists: group the pairs by list on the
+    //     device and scan every probed list once per kIvfNB of its queries (ivf_scan_shared_kernel)
+    const int64_t npairs = (int64_t)B * nprobe;
+    if (ix->ivf_share && npairs >= 1024 && !(ix->dtype != DT_F32 && niter == 4)) {
+        const int nlist = ix->ivf_nlist;
+        if ((rc = ensure_buf(&ix->ivf_group, &ix->ivf_group_cap, 3 * (int64_t)nlist + 2 + npairs)) != 0) return rc;
+        if ((rc = ensure_buf(&ix->ivf_partial, &ix->ivf_partial_cap, npairs * k)) != 0) return rc;
+        unsigned* cnt = ix->ivf_group;
+        unsigned* pair_start = cnt + nlist;
+        unsigned* item_start = pair_start + nlist + 1;
+        unsigned* sorted_pairs = item_start + nlist + 1;
+        {
+        EvScope ev(ix, EV_SCAN, st);
+        HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)nlist * sizeof(unsigned), st));
+        HIP_TRY(hipMemsetAsync(ix->ivf_partial, 0, (size_t)(npairs * k) * sizeof(u64), st));  // (an empty probe slot stays an empty list)
+        const unsigned pb = (unsigned)((npairs + 255) / 256);
+        hipLaunchKernelGGL(ivf_pair_count_kernel, dim3(pb), dim3(256), 0, st, ix->probe_keys, (int)npairs, cnt);
+        hipLaunchKernelGGL(ivf_pair_offsets_kernel, dim3(1), dim3(1024), 0, st, cnt, nlist, pair_start, item_start);
+        hipLaunchKernelGGL(ivf_pair_scatter_kernel, dim3(pb), dim3(256), 0, st, ix->probe_keys, (int)npairs, pair_start, cnt, sorted_pairs);
+        // work items <= sum over lists of ceil(pairs / kIvfNB) <= min(pairs, lists + pairs / kIvfNB): the grid covers the bound, surplus workgroups leave at once
+        const int64_t bound = std::min<int64_t>(npairs, (int64_t)nlist + npairs / kIvfNB);
+#define CODD_IVFS_LAUNCH(DT, NI, SL)                                                                                              \
+    hipLaunchKernelGGL((ivf_scan_shared_kernel<DT, NI, SL>), dim3((unsigned)bound), dim3(256), 0, st, ix->rows_ivf, ix->ivf_ids, \
+                       ix->ivf_offsets, pair_start, item_start, sorted_pairs, nlist, nprobe, ix->dpad, ix->qn, k, row_base, ix->ivf_partial)
+#define CODD_IVFS_NITER(DT, SL)                                       \
+    switch (niter) {                                                  \
+        case 1: CODD_IVFS_LAUNCH(DT, 1, SL); break;                   \
+        case 2: CODD_IVFS_LAUNCH(DT, 2, SL); break;                   \
+        case 3: CODD_IVFS_LAUNCH(DT, 3, SL); break;                   \
+        default: CODD_IVFS_LAUNCH(DT, 4, SL); break;                  \
+    }
+        if (ix->dtype == DT_F32) { if (slots == 1) { CODD_IVFS_NITER(DT_F32, 1) } else { CODD_IVFS_NITER(DT_F32, 2) } }
+        else if (ix->dtype == DT_BF16) { if (slots == 1) { CODD_IVFS_NITER(DT_BF16, 1) } else { CODD_IVFS_NITER(DT_BF16, 2) } }
+        else { if (slots == 1) { CODD_IVFS_NITER(DT_F16, 1) } else { CODD_IVFS_NITER(DT_F16, 2) } }
+#undef CODD_IVFS_NITER
+#undef CODD_IVFS_LAUNCH
+        HIP_TRY(hipGetLastError());
+        }
+        const int64_t ms = (int64_t)nprobe * k;
+        return launch_merge(ix->ivf_partial, B, ms, ms, k, (u64*)dev_keys, dev_dist, dev_rows, st);
+    }
     // 2. scan the probed lists; split each list over several blocks when the batch alone cannot fill the chip
     int split = (int)((4 * (int64_t)ix->num_cus + (int64_t)B * nprobe - 1) / ((int64_t)B * nprobe));
     split = split < 1 ? 1 : (split > 16 ? 16 : split);
     const int64_t m = (int64_t)nprobe * split * k;
     if ((rc = ensure_buf(&ix->ivf_partial, &ix->ivf_partial_cap, (int64_t)B * m)) != 0) return rc;
-    const int nchunks = ix->dpad / elems_per_chunk(ix->dtype);
-    const int niter = (nchunks + kWave - 1) / kWave;
-    const int slots = k <= 64 ? 1 : 2;
     const dim3 grid((unsigned)(nprobe * split), (unsigned)B), block(256);
 #define CODD_IVF_LAUNCH(DT, NI, SL)                                                                                          \
     hipLaunchKernelGGL((ivf_scan_kernel<DT, NI, SL>), grid, block, 0, st, ix->rows_ivf, ix->ivf_ids, ix->ivf_offsets,       \
@@ -2710,6 +2912,11 @@ int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {
     if (strcmp(key, "i8v2") == 0) {
         if (value < 0 || value > 2) return fail(CODD_KNN_EINVAL, "i8v2 must be 0, 1 or 2%s");
         ix->i8v2 = (int)value;
+        return CODD_KNN_OK;
+    }
+    if (strcmp(key, "ivf_share") == 0) {
+        if (value != 0 && value != 1) return fail(CODD_KNN_EINVAL, "ivf_share must be 0 or 1%s");
+        ix->ivf_share = (int)value;
         return CODD_KNN_OK;
     }
     if (strcmp(key, "fuse_fallback") == 0) {

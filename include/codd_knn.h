@@ -81,10 +81,11 @@ int codd_knn_reserve(codd_knn_index* index, int64_t rows);
  *           Storage grows as needed.  The host variant stages through a bounded device
  *           buffer (kept by the index between calls) and is synchronous; the device variant
  *           writes slots [first_slot, first_slot+n) asynchronously on `stream`: it is ordered on
- *           the device behind every search already enqueued on other streams of this index, and
- *           every later search on another stream waits for it on the device (no host
- *           synchronisation either way).  The `dev_vecs` buffer must stay valid until `stream`
- *           has run the call.
+ *           the device behind every search and every earlier upsert already enqueued on other
+ *           streams of this index (two writers on two streams run in call order), and every later
+ *           search, upsert or codd_knn_copy_rows_f32 on another stream waits for it on the device
+ *           (no host synchronisation either way).  The `dev_vecs` buffer must stay valid until
+ *           `stream` has run the call.
  */
 int codd_knn_upsert_host(codd_knn_index* index, const int64_t* host_slots, const float* host_vecs,
                          int64_t n, int normalize);
@@ -162,6 +163,9 @@ int codd_knn_approx_scores(codd_knn_index* index, const float* dev_queries, int 
  * over those lists, top-k with ORIGINAL row slots; with nprobe == nlist the result is bit-identical
  * to codd_knn_search.  Any of dev_keys / dev_dist / dev_rows may be NULL.
  */
+/* Stored rows [first, first+n) widened to fp32, device to device, asynchronously on `stream` (the IVF build's
+ * input).  Ordered like a search: behind every upsert enqueued before it on any stream, and a later upsert waits
+ * for it — which is why the index is not const here (ABI change in round 3). */
 int codd_knn_copy_rows_f32(codd_knn_index* index, int64_t first, int64_t n, float* dev_out, void* stream);
 int codd_knn_ivf_install(codd_knn_index* index, const float* dev_centroids, int nlist,
                          const int64_t* dev_perm, const int64_t* dev_offsets, void* stream);
@@ -187,22 +191,32 @@ int codd_knn_ivf_search(codd_knn_index* index, const float* dev_queries, int B, 
  *            badly — error norm above 0.04 — keeps the bf16 filter; so does, for the next
  *            "shadow8_cooldown" (256) searches, an index whose int8 passes leave more than
  *            "shadow8_max_surv" (4000) survivors per query or send queries to the fallback: dense
- *            clusters — unless the bf16 passes are seen to leave just as many), "sample_div8" (20:
- *            the int8 filter's thresholds come from a sample of 1/20 of the row tiles) and
+ *            clusters — unless the 2-byte passes are seen to leave at least half as many), "sample_div8" (28:
+ *            the int8 filter's thresholds come from a sample of 1/28 of the row tiles) and
  *            "sample_rounds8" (3: ... of at least that many tiles per compute unit for batches of
  *            more than 32 queries, up to a quarter of the corpus; performance only),
  *            "resident_q" (1: rows of <= 512 int8 elements keep the query block in LDS for the
  *            whole launch), "i8v2" (2: batches of 65..256 queries on rows of 384 or
  *            more elements take the second-generation int8 kernel, csrc/filter_i8.h; 1: only rows of
  *            more than 512 elements; 0: never), "i8v2_half" (1: batches of 65..128 queries take that kernel's
- *            8-query-block instantiation; 0: the first-generation kernel);
+ *            8-query-block instantiation; 0: the first-generation kernel),
+ *            "i8_pair" (1: that kernel synchronises once per two K-steps on rows of 768 / 1536 ... elements; 0: every
+ *            K-step), "per_block" (7, bit mask: the int8 bound uses each 32-row block's own quantisation error instead of
+ *            the corpus's worst — bit 0 in the tile kernel, bit 1 in finalize, bit 2 the block metadata by one LDS-DMA per
+ *            tile; 0 = the device-wide bound everywhere), "fuse_fallback" (1: batches above 64 queries answer candidate-list
+ *            overflows inside the finalize launch; 0: a launch of their own), "small_batch_max" (0; 1: a single query on
+ *            <= 2M-row int8 shadows is answered by ONE launch — measured slower than the three-launch chain, see
+ *            DESIGN.md §12, hence off), "ivf_share" (1: codd_knn_ivf_search scans a probed list once for all queries of the
+ *            batch that probe it, from 1,024 (query, list) pairs on; 0: once per pair),
+ *            "debug_fail_shadow_alloc" (tests: the next N allocations of the 2-byte shadow fail);
  *            "profile" = N keeps N (start, stop) HIP-event pairs, one per heavy-kernel launch,
  *            recorded on the launch stream (0 = off; resets the log)
  *   stats  : "searches", "scan_launches", "last_scan_blocks", "filter_passes",
  *            "fallback_queries", "filter_hits", "filter_survivors", "capacity_rows",
  *            "device_bytes", "num_cus", "workspaces" (stream workspaces in use), "shadow8_builds", "shadow8_passes", "i8v2_passes",
  *            "shadow16_builds" (the bf16 shadow is built lazily, by the first search that needs it), "all_normalized",
- *            "shadow8_cooldowns", "shadow8_eps_r_micro", and per kernel K in {scan, filter, sample, finalize}:
+ *            "shadow8_cooldowns", "shadow8_eps_r_micro", "shadow8_wide_blocks" (32-row blocks whose quantisation error is above
+ *            0.04: tolerated up to 1 % of the blocks), "shadow16_alloc_failures", "small_batch_passes", and per kernel K in {scan, filter, sample, finalize}:
  *            "events:K", "time_ns:K" (sum of the recorded launches; syncs on the last event)
  */
 int codd_knn_set_option(codd_knn_index* index, const char* key, int64_t value);

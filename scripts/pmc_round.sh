@@ -1,8 +1,8 @@
 #!/bin/bash
-# rocprofv3 counter passes over the headline bench (development tool).  usage: scripts/pmc_r2.sh <tag>
+# rocprofv3 counter passes over the headline bench (development tool).  usage: scripts/pmc_round.sh <tag>
 # Each pass is its own run with --kernel-trace only (gpurun refuses --pmc together with the tracing domains).
 set -e
-tag=${1:-r2}
+tag=${1:-r3}
 out=gpurun_out/pmc_$tag
 mkdir -p $out
 export TMPDIR=/tmp

@@ -185,7 +185,8 @@ def test_overflow_in_a_large_batch_is_answered_inside_the_finalize_launch(Index,
     for rep in range(2):
         dist, rows = ix.search(q, k)
         assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref), rep
-        assert ix.stat("fallback_queries") == (rep + 1) * len(hot)
+        # (the hot queries, and at most a couple of ordinary ones whose sample happened to anchor a weak threshold)
+        assert (rep + 1) * len(hot) <= ix.stat("fallback_queries") <= (rep + 1) * (len(hot) + 2)
     ix.close()
 
 

@@ -105,3 +105,37 @@ def test_two_ivf_shards_merge_to_the_whole_answer(env):
     assert recall >= 0.9
     for ix in (whole, shards[0][1], shards[1][1]):
         ix.close()
+
+
+@pytest.mark.parametrize(
+    "n,d,nlist,B,nprobe,k,dtype",
+    [
+        (60_000, 128, 64, 256, 8, 10, "f16"),     # 2,048 pairs over 64 lists: ~32 queries per list, 8 work items each
+        (60_000, 128, 64, 40, 64, 10, "f32"),     # exhaustive probe through the shared scan: must equal the flat search as well
+        (50_000, 768, 128, 128, 16, 100, "bf16"),  # k above 64: two top-k slots per lane
+        (30_000, 1024, 32, 256, 4, 10, "f16"),    # config 5's row width
+        (20_000, 100, 300, 70, 16, 10, "f32"),    # more lists than any query group touches; ragged row width
+    ],
+)
+def test_list_sharing_scan_returns_the_per_pair_scan_s_bits(env, n, d, nlist, B, nprobe, k, dtype):
+    """From 1,024 (query, list) pairs on, the pairs are grouped by list on the device and every probed list is read once per
+    group of its queries.  Same candidates, same canonical scores, same merge: the answer must be the per-pair scan's, bit for bit."""
+    torch, Index, ivf = env
+    x = clustered(torch, n, d, 2 * nlist)
+    ix = Index(d, dtype)
+    ix.upsert_device(0, x.contiguous())
+    ivf.build_ivf(ix, nlist, iters=3)
+    q = clustered(torch, B, d, 2 * nlist, seed=21)
+    q[B // 2 :] = q[0]                      # half of the batch probes the very same lists: one list, >100 pairs
+    q[1] = 0.0                              # and a zero query
+    ix.set_option("ivf_share", 0)
+    d0, r0 = ivf.search_ivf(ix, q, k, nprobe)
+    ix.set_option("ivf_share", 1)
+    d1, r1 = ivf.search_ivf(ix, q, k, nprobe)
+    assert torch.equal(r1, r0) and torch.equal(d1, d0)
+    d2, r2 = ivf.search_ivf(ix, q, k, nprobe)   # the grouping scratch is reused: a second call must not see the first one's counters
+    assert torch.equal(r2, r0) and torch.equal(d2, d0)
+    if nprobe == nlist:
+        df, rf = ix.search_tensors(q, k)
+        assert torch.equal(r1, rf) and torch.equal(d1, df)
+    ix.close()
