@@ -306,7 +306,7 @@ def measured_traffic(kernel, dtype, dim, n_local):
     """(bytes per launch, source) — HBM bytes from a COMMITTED rocprofv3 --pmc FETCH_SIZE pass, scaled by rows: counters
     cannot be read from inside this process, so the figure is a replayed constant of the newest profiles/traffic_r*.json
     that knows the kernel, not a measurement of this run.  (None, None) when no counter run exists for the kernel/shape."""
-    for name in ("traffic_r2.json", "traffic_r1.json"):
+    for name in ("traffic_r3.json", "traffic_r2.json", "traffic_r1.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)

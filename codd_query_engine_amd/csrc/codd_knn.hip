@@ -1056,38 +1056,53 @@ __global__ __launch_bounds__(256) void ivf_scan_shared_kernel(const void* __rest
     for (int b = 0; b < kIvfNB; ++b) L[b].init();
     const int64_t begin = offsets[list], end = offsets[list + 1];
     const uint4* base = reinterpret_cast<const uint4*>(rows_);
-    for (int64_t g4 = begin + wave * 4; g4 < end; g4 += 16) {
-        float w[4][NITER][E];
+    // the rows of step g4 + 16 are on their way while step g4 is scored (raw 16-byte chunks: half the registers of widened rows)
+    uint4 cur[4][NITER], nxt[4][NITER];
+    auto fetch = [&](int64_t g4, uint4 (&dst)[4][NITER]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int64_t row = g4 + r < end ? g4 + r : end - 1;
+            int64_t row = g4 + r < end ? g4 + r : end - 1;
+            row = row < begin ? begin : row;
             const uint4* p = base + row * (int64_t)nchunks + lane;
 #pragma unroll
-            for (int it = 0; it < NITER; ++it) {
-                uint4 c = make_uint4(0u, 0u, 0u, 0u);
-                if (lane + kWave * it < nchunks) c = p[kWave * it];
-                RT::widen(c, w[r][it]);
-            }
+            for (int it = 0; it < NITER; ++it) dst[r][it] = (lane + kWave * it < nchunks) ? p[kWave * it] : make_uint4(0u, 0u, 0u, 0u);
         }
+    };
+    if (end > begin) fetch(begin + wave * 4, cur);
+    for (int64_t g4 = begin + wave * 4; g4 < end; g4 += 16) {
+        if (g4 + 16 < end) fetch(g4 + 16, nxt);
+        float a[kIvfNB][4];
 #pragma unroll
-        for (int b = 0; b < kIvfNB; ++b) {
-            float a[4];
+        for (int b = 0; b < kIvfNB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[b][r] = 0.0f;
+#pragma unroll
+        for (int it = 0; it < NITER; ++it)   // (it-major as in the per-pair kernel: the same fma order per (row, query), the same bits)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float acc = 0.0f;
+                float w[E];
+                RT::widen(cur[r][it], w);
 #pragma unroll
-                for (int it = 0; it < NITER; ++it)
+                for (int b = 0; b < kIvfNB; ++b)
+                    if (b < nq) {
 #pragma unroll
-                    for (int e = 0; e < E; ++e) acc = __builtin_fmaf(qf[b][it][e], w[r][it][e], acc);
-                a[r] = acc;
+                        for (int e = 0; e < E; ++e) a[b][r] = __builtin_fmaf(qf[b][it][e], w[e], a[b][r]);
+                    }
             }
-            const float y = butterfly_sum4(a[0], a[1], a[2], a[3], lane);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(y), 16 * r));
-                if (g4 + r < end && b < nq) L[b].offer(make_key(sc, row_base + ids[g4 + r]), k, lane);
+        for (int b = 0; b < kIvfNB; ++b)
+            if (b < nq) {
+                const float y = butterfly_sum4(a[b][0], a[b][1], a[b][2], a[b][3], lane);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(y), 16 * r));
+                    if (g4 + r < end) L[b].offer(make_key(sc, row_base + ids[g4 + r]), k, lane);
+                }
             }
-        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int it = 0; it < NITER; ++it) cur[r][it] = nxt[r][it];
     }
     __shared__ u64 lds[4 * kIvfNB * SLOTS * kWave];
 #pragma unroll
@@ -2778,7 +2793,9 @@ int codd_knn_ivf_search(codd_knn_index* ix, const float* dev_queries, int B, int
     // 2a. a batch with enough (query, list) pairs to fill the chip without splitting lists: group the pairs by list on the
     //     device and scan every probed list once per kIvfNB of its queries (ivf_scan_shared_kernel)
     const int64_t npairs = (int64_t)B * nprobe;
-    if (ix->ivf_share && npairs >= 1024 && !(ix->dtype != DT_F32 && niter == 4)) {
+    //     (worth it once a list is probed by two queries or more on average: below that every work item holds one pair and the
+    //     grouping launches are pure overhead — 12.5M x 1024 fp16, 2,048 lists, B = 256: nprobe 8 5.98 ms per pair vs 7.22 shared)
+    if (ix->ivf_share && npairs >= 1024 && npairs >= 2 * (int64_t)ix->ivf_nlist && !(ix->dtype != DT_F32 && niter == 4)) {
         const int nlist = ix->ivf_nlist;
         if ((rc = ensure_buf(&ix->ivf_group, &ix->ivf_group_cap, 3 * (int64_t)nlist + 2 + npairs)) != 0) return rc;
         if ((rc = ensure_buf(&ix->ivf_partial, &ix->ivf_partial_cap, npairs * k)) != 0) return rc;

@@ -56,10 +56,10 @@ def main():
 
     q = draw(256, 9999)
     k = 10
-    _, truth = ix.search_tensors(q[:64], k)
+    _, truth = ix.search_tensors(q, k)
     out = {"rows": a.rows, "dim": a.dim, "dtype": a.dtype, "ingest_s": t_ingest, "ivf_build_s": t_build, "ivf": stats, "nprobe": a.nprobe, "noise": a.noise}
     for nprobe in sorted({1, a.nprobe, 4 * a.nprobe}):
-        _, got = ivf.search_ivf(ix, q[:64], k, nprobe)
+        _, got = ivf.search_ivf(ix, q, k, nprobe)
         out[f"recall@10_nprobe{nprobe}"] = (got.unsqueeze(2) == truth.unsqueeze(1)).any(dim=2).float().mean().item()
 
     def timed(fn, B, iters=30):
@@ -79,6 +79,12 @@ def main():
     for B in (1, 32, 256):
         out[f"ivf_B{B}"] = timed(lambda qq: ivf.search_ivf(ix, qq, k, a.nprobe), B)
         out[f"flat_B{B}"] = timed(lambda qq: ix.search_tensors(qq, k), B)
+    # batch 256: the per-pair scan against the list-sharing scan (a probed list read once per 4 of its queries), two probe depths
+    for nprobe in (1, a.nprobe, 4 * a.nprobe):
+        for share in (0, 1):
+            ix.set_option("ivf_share", share)
+            out[f"ivf_B256_nprobe{nprobe}_share{share}"] = timed(lambda qq: ivf.search_ivf(ix, qq, k, nprobe), 256)
+    ix.set_option("ivf_share", 1)
     elem = 4 if a.dtype == "f32" else 2
     out["bytes_flat_pass_shadow"] = a.rows * a.dim * 2
     out["bytes_ivf_per_query"] = a.nprobe * (a.rows / a.nlist) * a.dim * elem
