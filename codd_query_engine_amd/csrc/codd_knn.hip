@@ -1241,7 +1241,8 @@ struct codd_knn_index : WorkBufs {
     int small_batch_max = 0;      // 1: a single query is answered in one launch by small_batch_kernel where it applies.  OFF by default: measured SLOWER than the
                                   // six-launch chain (1M x 768, B = 1: kernel 0.27 ms, p50 0.33 ms against 0.25 ms; profiles/r3/small_batch_latency.txt)
     int64_t stat_small_batch = 0;
-    int per_block = 7;            // the int8 bound per 32-row block: bit 0 in i8_tile_kernel, bit 1 in finalize ("per_block" option; 0 = the device-wide bound everywhere)
+    int per_block = 7;            // the int8 bound per 32-row block: bit 0 in i8_tile_kernel, bit 1 in finalize ("per_block" option; 0 = the device-wide bound everywhere;
+                                  // bit 2 chose between block metadata and per-row scales in the tile kernel's filter pass until the per-row path was removed: ignored)
     int i8_pair = 1;              // rows of 6, 12, ... K-steps: the staged tile program with one workgroup barrier per two K-steps ("i8_pair" option: 0 = one per K-step)
     int sample_div8 = 28;         // its thresholds come from a larger sample (the int8 slack is ~5x the bf16 one)
     int sample_rounds8 = 3;       // ... of at least this many rounds of workgroups (one tile each) when the batch has more than 32 queries
@@ -1994,7 +1995,7 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
 #define CODD_LAUNCH_TILE8(S3, NQB, RES)                                                                                                              \
     hipLaunchKernelGGL((i8_tile_kernel<MODE_FILTER, S3, NQB, RES>), g, b, i8_lds_bytes(MODE_FILTER), st, shadow, qfrag, n, nsteps, ntiles, (int64_t)1, \
                        (ix->per_block & 1) ? ix->thr + kTileQ : ix->thr, CODD_STAMP_BUF, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, ix->rscale, ix->qmeta, \
-                       (ix->per_block & 4) ? ix->bmeta : nullptr, (ix->per_block & 1) ? 1.0f : 0.0f)
+                       ix->bmeta, (ix->per_block & 1) ? 1.0f : 0.0f)
             const bool res = i8_tile_resident(nsteps, nbq) && ix->resident_q;
             // tile structure: rows of 6, 12, ... K-steps (768 elements: the headline shape) run the staged program with one barrier
             // per TWO K-steps; other multiples of 3 one per K-step; the rest the generic interval loop

@@ -202,10 +202,15 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned n_rows = (unsigned)n;  // (row slots are 32-bit: keys carry them in their low word)
 
-    const int64_t G = gridDim.x;
-    const int64_t first_u = blockIdx.x;
-    const int64_t my_tiles = ntiles_run > (int64_t)blockIdx.x ? (ntiles_run - blockIdx.x + G - 1) / G : 0;
-    const int T = (int)(my_tiles * nsteps);  // K-steps of this workgroup
+    // tile ordinals and strides are 32-bit in here (row slots are: 2^32 rows are 2^24 tiles) — the 64-bit cursors of round 2 and
+    // the round-3 additions together pushed the kernel past its 102 scalar registers: hipcc parked the query slices' buffer
+    // descriptor in lanes of a vector register and re-read it with four v_readlane in front of EVERY slice DMA (2,300 of them
+    // in the unrolled program, 16 per K-step and wave)
+    const int G = (int)gridDim.x;
+    const int first_u = (int)blockIdx.x;
+    const int tstride = (int)tile_stride;
+    const int my_tiles = (int)ntiles_run > first_u ? ((int)ntiles_run - first_u + G - 1) / G : 0;
+    const int T = my_tiles * nsteps;  // K-steps of this workgroup
     if (T == 0) return;
 
     if (MODE == MODE_FILTER) {
@@ -243,8 +248,8 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
 
     const int lane16 = lane * 16;
     const i32x4 rsrc_q = i8_rsrc(qfrag8, (unsigned)(nsteps * kI8SliceBytes));
-    const int64_t step_bytes = 4096;                       // 4 pieces x 1 KiB: this wave's 32 rows x 128 elements
-    const int64_t tile_bytes = (int64_t)8 * nsteps * step_bytes;
+    constexpr int step_bytes = 4096;                       // 4 pieces x 1 KiB: this wave's 32 rows x 128 elements
+    const int tile_bytes = 8 * nsteps * step_bytes;
 
     float u_max = 0.0f;  // FILTER: max over the batch of B(q) / qscale_q (uniform; set behind the prologue's barrier)
     i32x4 acc[2][NQB];
@@ -254,14 +259,14 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         for (int qb = 0; qb < NQB; ++qb) acc[rs][qb] = i32x4{0, 0, 0, 0};
 
     // ---- corpus fragments: HBM -> registers, ring of 3 K-steps, the cursor runs 2 steps ahead (1 for a lagging wave) ----
-    int64_t l_u = first_u;  // run-tile ordinal of the next step to load
+    int l_u = first_u;  // run-tile ordinal of the next step to load
     int l_s = 0, l_left = T;
     u32x4 ring[3][4];
     auto load_a = [&](u32x4(&dst)[4]) __attribute__((always_inline)) {
 #ifdef CODD_I8_EXP_SAMETILE
-        const char* base = reinterpret_cast<const char*>(shadow8) + ((int64_t)wave * nsteps + l_s) * step_bytes;  // diagnostic: corpus served by L2
+        const char* base = reinterpret_cast<const char*>(shadow8) + (wave * nsteps + l_s) * step_bytes;  // diagnostic: corpus served by L2
 #else
-        const char* base = reinterpret_cast<const char*>(shadow8) + (l_u * tile_stride) * tile_bytes + ((int64_t)wave * nsteps + l_s) * step_bytes;
+        const char* base = reinterpret_cast<const char*>(shadow8) + (int64_t)(l_u * tstride) * tile_bytes + (wave * nsteps + l_s) * step_bytes;
 #endif
         const i32x4 r = i8_rsrc(base, 4096);
         i8_load_b128_nt<0>(dst[0], lane16, r);
@@ -277,9 +282,9 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     i32x4 a_rsrc = {0, 0, 0, 0};
     auto load_a_begin = [&]() __attribute__((always_inline)) {
 #ifdef CODD_I8_EXP_SAMETILE
-        const char* base = reinterpret_cast<const char*>(shadow8) + ((int64_t)wave * nsteps + l_s) * step_bytes;
+        const char* base = reinterpret_cast<const char*>(shadow8) + (wave * nsteps + l_s) * step_bytes;
 #else
-        const char* base = reinterpret_cast<const char*>(shadow8) + (l_u * tile_stride) * tile_bytes + ((int64_t)wave * nsteps + l_s) * step_bytes;
+        const char* base = reinterpret_cast<const char*>(shadow8) + (int64_t)(l_u * tstride) * tile_bytes + (wave * nsteps + l_s) * step_bytes;
 #endif
         a_rsrc = i8_rsrc(base, 4096);
     };
@@ -314,16 +319,16 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     // The host keeps rscale[r] = NaN for count <= r < the next multiple of 256: `acc * NaN >= thr` is false for every
     // threshold, so the epilogue needs no row < n test; tiles past the corpus (padding intervals) read zeros.
     const int lane4 = lane * 4;
-    auto rs_dma = [&](int64_t u, int ord) __attribute__((always_inline)) {
-        if (MODE == MODE_FILTER && bmeta) {
+    auto rs_dma = [&](int u, int ord) __attribute__((always_inline)) {
+        if constexpr (MODE == MODE_FILTER) {
             // the tile's eight blocks' {scale, error norm}: dwords [2 w], [2 w + 1] of the buffer belong to wave w (one 256-byte DMA:
             // 32 blocks from the tile's first one — the allocation has the head room; every wave writes the same bytes)
-            const int64_t blk0 = u * tile_stride * (kTileRows / 32);
-            const int64_t nblk = (n + 31) / 32;
+            const unsigned blk0 = (unsigned)(u * tstride) * (unsigned)(kTileRows / 32);
+            const unsigned nblk = (n_rows + 31u) / 32u;
             i8_dma_b32(lds0 + (unsigned)(4 * kI8SliceBytes + kI8Words * 4 + ((ord & 1) * kI8RsStride) * 4), lane4,
                        i8_rsrc(bmeta + (blk0 < nblk ? blk0 : 0), blk0 < nblk ? 256u : 0u), 0);
         } else {
-        const int64_t row0 = u * tile_stride * kTileRows;
+        const int64_t row0 = (int64_t)(u * tstride) * kTileRows;
         const int64_t bound = (n + kTileRows - 1) / kTileRows * kTileRows;
         const int64_t left = bound - row0;
         const int rows_here = left >= kTileRows ? kTileRows : (left > 0 ? (int)left : 0);
@@ -349,20 +354,20 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         float ueb;                 // U * eb: what the pre-test adds to acc * rsl (uniform)
         u32x4 thw[NQB / 8];        // the lane's NQB pre-test thresholds, two bf16 per word (see the kernel's set-up)
     };
-    auto epi_begin = [&](int64_t cu, int ord, bool valid) __attribute__((always_inline)) {
+    auto epi_begin = [&](int cu, int ord, bool valid) __attribute__((always_inline)) {
         // lane coordinates re-derived behind an opaque asm: hipcc otherwise hoists every per-query-block address of this
         // body out of the interval loop and keeps dozens of registers of loop invariants alive across the MFMA phases
         EpiCtx e;
         int l = lane;
         asm volatile("" : "+v"(l));
         const int c = l & 15;
-        const int64_t tile = cu * tile_stride;
+        const int tile = cu * tstride;
         e.par = kLists == 2 ? (unsigned)(ord & 1) : 0u;
-        e.wrow0 = (unsigned)(tile * kTileRows) + (unsigned)(wave * 32);
+        e.wrow0 = (unsigned)tile * (unsigned)kTileRows + (unsigned)(wave * 32);
         // ONE scale per 32-row block (shadow8_from_rows_kernel), so the wave's rows share it and the pre-test on a pair's
         // largest accumulator is EXACT at pair level: it passes iff some value of the pair passes.  Rows past the count
         // carry NaN: the block's first row exists whenever any of its rows does, and the per-value test masks the others.
-        const float rs0 = lds_rs[(ord & 1) * kI8RsStride + (bmeta ? 2 * wave : 32 * wave)], eb0 = bmeta ? lds_rs[(ord & 1) * kI8RsStride + 2 * wave + 1] : 0.0f;
+        const float rs0 = lds_rs[(ord & 1) * kI8RsStride + 2 * wave], eb0 = lds_rs[(ord & 1) * kI8RsStride + 2 * wave + 1];
         e.rsl = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(valid ? rs0 : __builtin_nanf(""))));
         e.inv_rsl = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(1.0f / (valid ? rs0 : __builtin_nanf("")))));
         e.eb = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(eb0))) * eb_scale;  // (eb_scale 0: the device-wide bound, thr = L - eps(q))
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
 #endif
         }
     };
-    auto epilogue = [&](int64_t cu, int ord) __attribute__((always_inline)) {
+    auto epilogue = [&](int cu, int ord) __attribute__((always_inline)) {
 #ifdef CODD_I8_EXP_NOEPI
         if (true) {
 #pragma unroll
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         } else {
             int c = lane & 15, lg = lane >> 4;
             asm volatile("" : "+v"(c), "+v"(lg));
-            const int64_t tile = cu * tile_stride;
+            const int tile = cu * tstride;
             const unsigned par = kLists == 2 ? (unsigned)(ord & 1) : 0u;
             const float* rsb = lds_rs + (ord & 1) * kI8RsStride;
             const f32x4 rsc0 = *reinterpret_cast<const f32x4*>(rsb + wave * 32 + 4 * lg);
@@ -472,13 +477,13 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             // first) packs into one int — |accumulator| <= 127 * 127 * 4096 < 2^26, five bits for the row — and the fold across
             // the lane's 8 values and the 4 lanes that hold a query is integer max + two lane swaps; one lane per query builds
             // the key.  (INT_MIN: a row past n.)
-            const bool ragged = (tile + 1) * kTileRows > n;
+            const bool ragged = (int64_t)(tile + 1) * kTileRows > n;
             const float rsl = fmaxf(fmaxf(fmaxf(rsc0[0], rsc0[1]), fmaxf(rsc0[2], rsc0[3])), fmaxf(fmaxf(rsc1[0], rsc1[1]), fmaxf(rsc1[2], rsc1[3])));
             // (the key is built by lanes 0..15, whose rows 0..3 of the block are valid whenever any row of it is)
             int code[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) code[i] = 31 - (4 * lg + 16 * (i >> 2) + (i & 3));
-            const unsigned wrow0 = (unsigned)(tile * kTileRows) + (unsigned)(wave * 32);
+            const unsigned wrow0 = (unsigned)tile * (unsigned)kTileRows + (unsigned)(wave * 32);
             auto fold = [&](auto RAGGED) __attribute__((always_inline)) {
 #pragma unroll
                 for (int qb = 0; qb < NQB; ++qb) {
@@ -589,12 +594,12 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         unsigned long long st_pre = 0, st_vm = 0, st_mfma = 0, st_sync = 0, st_epi = 0, st_iv = 0;
         const unsigned long long st_begin = __builtin_readcyclecounter();
 #endif
-        int64_t c_u = first_u;   // compute cursor (this wave's step s = t - LAG)
+        int c_u = first_u;       // compute cursor (this wave's step s = t - LAG)
         int c_s = 0, c_ord = 0;
-        int64_t w_u = first_u;   // workgroup cursor (step t)
+        int w_u = first_u;       // workgroup cursor (step t)
         int w_s = 0, w_ord = 0;
         bool pending = false;    // a finished tile whose epilogue has not run yet
-        int64_t p_u = 0;
+        int p_u = 0;
         int p_ord = 0;
         int pub_ord = 0;         // SAMPLE: next tile ordinal to publish
         const int TI = T + (CODD_I8_LAG ? 1 : 0);
@@ -745,7 +750,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                     if (tid < 256) {
                         u64 key = lds_k[par * 256 + tid];
                         if (key) key = make_key(key_score(key) * qscale[tid], key_row(key));  // the fold ran on acc * rscale
-                        bucket_key[(int64_t)tid * ntiles_run + (first_u + (int64_t)pub_ord * G)] = key;
+                        bucket_key[(int64_t)tid * ntiles_run + (first_u + pub_ord * G)] = key;
                         lds_k[par * 256 + tid] = 0ull;
                     }
                     ++pub_ord;
@@ -761,7 +766,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             constexpr bool kFuse = CODD_I8_FUSE_EPI && MODE == MODE_FILTER;
             const std::integral_constant<bool, kFuse> fuse{};
             const std::false_type no{};
-            for (int64_t o = 0; o < my_tiles; ++o) {
+            for (int o = 0; o < my_tiles; ++o) {
                 EpiCtx ectx;
                 if constexpr (kFuse) {
                     // tile o - 1 (this workgroup's previous one) is tested inside the first K-step below; the first tile has
@@ -844,7 +849,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         if (MODE == MODE_SAMPLE && pub_ord < my_tiles && tid < 256) {
             u64 key = lds_k[(kLists == 2 ? (pub_ord & 1) * 256 : 0) + tid];
             if (key) key = make_key(key_score(key) * qscale[tid], key_row(key));
-            bucket_key[(int64_t)tid * ntiles_run + (first_u + (int64_t)pub_ord * G)] = key;
+            bucket_key[(int64_t)tid * ntiles_run + (first_u + pub_ord * G)] = key;
         }
     };
     if (CODD_I8_LAG && wave >= 4) run(std::integral_constant<int, CODD_I8_LAG>{});

@@ -70,3 +70,10 @@ def test_hand_issued_vector_memory_operations_carry_their_own_wait_states():
                     waits += int(m.group(1)) + 1 if m else 1
                 assert waits >= 5, f"hand-issued load without its wait states: {lines}"
     assert loads >= 60, loads  # 13 per interval x 6 unrolled intervals, prologue, ...
+    # and the headline instantiation keeps every scalar in scalar registers.  Round 3 first shipped it 12 SGPRs over the budget:
+    # no scratch, no VGPR spill — hipcc parks SGPRs in lanes of a spare vector register, which the resource report above does
+    # not show — and the query slices' buffer descriptor was re-read with four v_readlane in front of each of the 24 slice DMA
+    # of a tile (2,389 in the unrolled program): the kernel lost what the round's schedule changes had gained.
+    m = re.findall(r"\.sgpr_spill_count:\s+(\d+)", text)
+    assert m and all(int(v) == 0 for v in m), m
+    assert len(re.findall(r"\bv_readlane_b32\b", text)) <= 16, "SGPR spill reloads inside i8_tile_kernel<FILTER, 2, 16>"
