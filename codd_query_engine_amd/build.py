@@ -95,7 +95,7 @@ def resource_report(remarks: str) -> str:
     """Condense -Rpass-analysis=kernel-resource-usage into one line per kernel."""
     rows, cur = [], {}
     for line in remarks.splitlines():
-        m = re.search(r"remark:\s+(Function Name|VGPRs|AGPRs|SGPRs|VGPRs Spill|SGPRs Spill|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]):\s*(\S+)", line)
+        m = re.search(r"remark:\s+(Function Name|VGPRs|AGPRs|TotalSGPRs|SGPRs|VGPRs Spill|SGPRs Spill|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]):\s*(\S+)", line)
         if not m:
             continue
         key, val = m.group(1), m.group(2)
@@ -111,11 +111,12 @@ def resource_report(remarks: str) -> str:
             cur[key] = val
     if cur:
         rows.append(cur)
-    out = ["%-64s %5s %5s %6s %6s %4s %6s" % ("kernel", "vgpr", "sgpr", "vspill", "scratch", "occ", "lds")]
+    # (sspill: SGPRs hipcc parked in lanes of a vector register — no scratch, no VGPR spill, but a v_readlane in front of every use)
+    out = ["%-64s %5s %5s %6s %6s %4s %6s %6s" % ("kernel", "vgpr", "sgpr", "vspill", "scratch", "occ", "lds", "sspill")]
     for r in rows:
-        out.append("%-64s %5s %5s %6s %6s %4s %6s" % (
-            r["name"][-64:], r.get("VGPRs", "?"), r.get("SGPRs", "?"), r.get("VGPRs Spill", "?"),
-            r.get("ScratchSize [bytes/lane]", "?"), r.get("Occupancy [waves/SIMD]", "?"), r.get("LDS Size [bytes/block]", "?")))
+        out.append("%-64s %5s %5s %6s %6s %4s %6s %6s" % (
+            r["name"][-64:], r.get("VGPRs", "?"), r.get("TotalSGPRs", r.get("SGPRs", "?")), r.get("VGPRs Spill", "?"),
+            r.get("ScratchSize [bytes/lane]", "?"), r.get("Occupancy [waves/SIMD]", "?"), r.get("LDS Size [bytes/block]", "?"), r.get("SGPRs Spill", "?")))
     return "\n".join(out)
 
 

@@ -1243,7 +1243,8 @@ struct codd_knn_index : WorkBufs {
     int64_t stat_small_batch = 0;
     int per_block = 7;            // the int8 bound per 32-row block: bit 0 in i8_tile_kernel, bit 1 in finalize ("per_block" option; 0 = the device-wide bound everywhere;
                                   // bit 2 chose between block metadata and per-row scales in the tile kernel's filter pass until the per-row path was removed: ignored)
-    int i8_pair = 1;              // rows of 6, 12, ... K-steps: the staged tile program with one workgroup barrier per two K-steps ("i8_pair" option: 0 = one per K-step)
+    int i8_pair = 2;              // rows of 6, 12, ... K-steps: the staged tile program with one workgroup barrier per two K-steps ("i8_pair" option: 0 = one per K-step;
+                                  // 2 = ... and rows of exactly 6 K-steps its static form, i8_tile_kernel<., 3, ., false>)
     int sample_div8 = 28;         // its thresholds come from a larger sample (the int8 slack is ~5x the bf16 one)
     int sample_rounds8 = 3;       // ... of at least this many rounds of workgroups (one tile each) when the batch has more than 32 queries
     uint4* shadow8 = nullptr;
@@ -1999,13 +2000,17 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
             const bool res = i8_tile_resident(nsteps, nbq) && ix->resident_q;
             // tile structure: rows of 6, 12, ... K-steps (768 elements: the headline shape) run the staged program with one barrier
             // per TWO K-steps; other multiples of 3 one per K-step; the rest the generic interval loop
+            // ("i8_pair" = 2, the default: rows of exactly 6 K-steps take that program with every cursor a compile-time constant)
             const bool pair = nsteps % 6 == 0 && ix->i8_pair;
+            const bool static6 = nsteps == 6 && ix->i8_pair == 2;
             if (nbq == 8) {
                 if (res) { if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(1, 16, true); else CODD_LAUNCH_TILE8(0, 16, true); }
+                else if (static6) CODD_LAUNCH_TILE8(3, 16, false);
                 else if (pair) CODD_LAUNCH_TILE8(2, 16, false);
                 else { if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(1, 16, false); else CODD_LAUNCH_TILE8(0, 16, false); }
             } else {
                 if (res) { if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(1, 8, true); else CODD_LAUNCH_TILE8(0, 8, true); }
+                else if (static6) CODD_LAUNCH_TILE8(3, 8, false);
                 else if (pair) CODD_LAUNCH_TILE8(2, 8, false);
                 else { if (nsteps % 3 == 0) CODD_LAUNCH_TILE8(1, 8, false); else CODD_LAUNCH_TILE8(0, 8, false); }
             }
@@ -2953,7 +2958,7 @@ int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {
         return CODD_KNN_OK;
     }
     if (strcmp(key, "i8_pair") == 0) {
-        if (value != 0 && value != 1) return fail(CODD_KNN_EINVAL, "i8_pair must be 0 or 1%s");
+        if (value < 0 || value > 2) return fail(CODD_KNN_EINVAL, "i8_pair must be 0, 1 or 2%s");
         ix->i8_pair = (int)value;
         return CODD_KNN_OK;
     }

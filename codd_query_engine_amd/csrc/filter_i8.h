@@ -106,6 +106,11 @@ __device__ __forceinline__ void i8_dma_b128(unsigned lds_addr, int voff, i32x4 r
                  "s"(__builtin_amdgcn_readfirstlane(soff))
                  : "memory", "m0");
 }
+// the same for operands that ARE scalar registers already (the static tile program: a v_readfirstlane hipcc does not fold costs a
+// vector register for its source, and that one — loop-invariant — was spilled to scratch and reloaded with a vmcnt(0) per tile)
+__device__ __forceinline__ void i8_dma_b128_s(unsigned lds_addr, int voff, i32x4 rsrc, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory", "m0");
+}
 // 64 lanes x 4 bytes: global (rsrc + voff + soff) -> LDS [lds_addr + 4 * lane]
 __device__ __forceinline__ void i8_dma_b32(unsigned lds_addr, int voff, i32x4 rsrc, int soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 3\n\tbuffer_load_dword %1, %2, %3 offen lds" ::"s"(__builtin_amdgcn_readfirstlane((int)lds_addr)), "v"(voff), "s"(rsrc),
@@ -176,8 +181,12 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     // SAMPLE: rscale[row] (per row; NaN past the count), no thresholds.
     static_assert(MODE == MODE_FILTER || MODE == MODE_SAMPLE, "filter and sample passes only");
     constexpr bool STEPS3 = TS != 0;
-    constexpr bool kPair = TS == 2;
-    static_assert(TS >= 0 && TS <= 2 && !(kPair && (RES || CODD_I8_LAG)), "pair barriers: staged tile-structured program only");
+    constexpr bool kPair = TS >= 2;
+    // TS = 3: the pair program for rows of EXACTLY 6 K-steps (768 elements, the headline shape), every cursor of the tile loop a
+    // compile-time constant (run_static6 below)
+    constexpr bool kStatic6 = TS == 3;
+    static_assert(TS >= 0 && TS <= 3 && !(kPair && (RES || CODD_I8_LAG)), "pair barriers: staged tile-structured program only");
+    static_assert(!kStatic6 || (MODE == MODE_FILTER && !CODD_I8_FUSE_EPI && !CODD_I8_SPREAD_VM), "the static six-step program: filter pass, standalone epilogue");
     static_assert(NQB == 16 || NQB == 8, "256 or 128 queries");
     constexpr int kDmaPerSlice = NQB / 4;                 // this wave's 1 KiB chunks of a slice
     constexpr int kDmaPerIv = RES ? 0 : kDmaPerSlice;     // slice DMA per interval
@@ -594,6 +603,88 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         unsigned long long st_pre = 0, st_vm = 0, st_mfma = 0, st_sync = 0, st_epi = 0, st_iv = 0;
         const unsigned long long st_begin = __builtin_readcyclecounter();
 #endif
+        int pub_ord = 0;         // SAMPLE: next tile ordinal to publish
+        if constexpr (kStatic6) {
+            // ---- the static six-step tile program -----------------------------------------------------------------------------
+            // The generic interval carries four cursors (load, slice, compute, workgroup) through compare-and-select chains and
+            // rebuilds two buffer descriptors from 64-bit products: 74 scalar instructions per K-step and wave in front of 64
+            // MFMAs (rocprofv3 SQ_INSTS_SALU), issued by all eight waves at the same moment — behind a barrier — with the matrix
+            // pipe idle.  With 6 K-steps per tile everything is a constant of the unrolled interval index i: the slice of step
+            // t + 2 is slice (i + 2) % 6 in LDS slot ((i + 2) & 3) ^ 2 (o & 1) [6 o + i = 2 o + i mod 4], the corpus step to load is
+            // step (i + 2) % 6 of this tile (i < 4) or of the next one, whose base address is one 64-bit add per TILE away, and
+            // the block metadata is requested once per tile (interval 0) — which makes the number of operations per interval
+            // 9, 8, 8, 8, 8, 8 (1 + kDmaPerSlice + 4 in general) and the counted waits below.
+            static_assert(LAG == 0, "no lagging half");
+            constexpr int kOps0 = 1 + kDmaPerSlice + kAPerIv, kOpsN = kDmaPerSlice + kAPerIv;
+            const unsigned ldsw = lds0 + (unsigned)(wave * 1024);   // this wave's share of a slice slot
+            const int wq = wave * 1024;                              // ... and of a slice in the query buffer
+            int u = first_u;                                          // run-tile ordinal of tile o
+            const char* A_cur = reinterpret_cast<const char*>(shadow8) + (int64_t)(u * tstride) * tile_bytes + wave * (6 * step_bytes);
+            const int64_t dA = (int64_t)(G * tstride) * tile_bytes;
+            unsigned px = 0u;                                         // 2 slots' bytes for odd tiles: slot ^ 2
+            auto s_interval = [&](auto I_, const char* A_next) __attribute__((always_inline)) {
+                constexpr int i = decltype(I_)::value;
+                constexpr int ci = i % 3, li = (ci + 2) % 3;
+                constexpr int st = (i + 2) % 6;                       // the step whose slice and corpus fragments are requested here
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned qaddr = lds0 + (((unsigned)((i & 3) * kSlotBytes)) ^ px) + (unsigned)lane16;
+                i32x4 b[kBD];
+                if (CODD_I8_EARLY_FRAGS) frag_prefetch(b, qaddr);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (i == 0) rs_dma(u, (int)(px != 0u));    // (tile parity picks the scale buffer: ord & 1)
+#ifndef CODD_I8_EXP_NODMA
+                {
+                    const unsigned dst = ldsw + (((unsigned)(((i + 2) & 3) * kSlotBytes)) ^ px);
+#pragma unroll
+                    for (int j = 0; j < kDmaPerSlice; ++j) i8_dma_b128_s(dst + j * 8192, lane16, rsrc_q, wq + st * kI8SliceBytes + j * 8192);
+                }
+#endif
+                {
+                    const char* base = (i < 4 ? A_cur : A_next) + st * step_bytes;
+                    const i32x4 r = i8_rsrc(base, 4096);
+                    i8_load_b128_nt<0>(ring[li][0], lane16, r);
+                    i8_load_b128_nt<1024>(ring[li][1], lane16, r);
+                    i8_load_b128_nt<2048>(ring[li][2], lane16, r);
+                    i8_load_b128_nt<3072>(ring[li][3], lane16, r);
+                }
+                // the corpus step requested two intervals ago: younger are the previous interval's operations and this one's
+                i8_wait_vm<(i == 0 ? kOpsN + kOps0 : (i == 1 ? kOps0 + kOpsN : 2 * kOpsN))>(ring[ci][0], ring[ci][1], ring[ci][2], ring[ci][3]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!CODD_I8_EARLY_FRAGS) frag_prefetch(b, qaddr);
+                mfma_step(std::integral_constant<int, ci>{}, std::integral_constant<bool, i == 0>{}, std::false_type{}, b, qaddr, nullptr, [](auto) {});
+                if constexpr (i & 1) {
+                    // the slices of steps t + 1 and t + 2 (and, i == 1, the tile's block metadata) have landed: younger than this
+                    // interval's slice DMA are only its corpus loads
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kAPerIv) : "memory");
+                }
+            };
+            for (int o = 0; o < my_tiles; ++o) {
+                const char* A_next = o + 1 < my_tiles ? A_cur + dA : A_cur;   // (past the last tile the loads stay on it: unconditional, never consumed)
+                s_interval(std::integral_constant<int, 0>{}, A_next);
+                s_interval(std::integral_constant<int, 1>{}, A_next);
+                // behind the barrier of the tile's second interval every wave has folded the previous tile: its hit count is stable
+                if (o >= 1) {
+                    const unsigned cnt = lds_w[256];
+                    if (cnt > (unsigned)(CODD_FLUSH_AT)) {
+                        int tid_f = tid;
+                        asm volatile("" : "+v"(tid_f));  // (or hipcc hoists &hit_cnt[tid] out of the tile loop)
+                        flush_hits_binned(lds_hits, cnt < kListCap ? cnt : kListCap, tid_f, lds_w + 832, hits, hit_cnt, cap_q, reinterpret_cast<const float*>(lds_w + 320));
+                        __syncthreads();
+                        if (tid == 0) lds_w[256] = 0u;
+                    }
+                }
+                s_interval(std::integral_constant<int, 2>{}, A_next);
+                s_interval(std::integral_constant<int, 3>{}, A_next);
+                s_interval(std::integral_constant<int, 4>{}, A_next);
+                s_interval(std::integral_constant<int, 5>{}, A_next);
+                epilogue(u, (int)(px != 0u));
+                u += G;
+                A_cur = A_next;
+                px ^= (unsigned)(2 * kSlotBytes);
+            }
+            // (the corpus loads of the last two intervals are never consumed: nothing of this wave may be in flight past this point)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
         int c_u = first_u;       // compute cursor (this wave's step s = t - LAG)
         int c_s = 0, c_ord = 0;
         int w_u = first_u;       // workgroup cursor (step t)
@@ -601,7 +692,6 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         bool pending = false;    // a finished tile whose epilogue has not run yet
         int p_u = 0;
         int p_ord = 0;
-        int pub_ord = 0;         // SAMPLE: next tile ordinal to publish
         const int TI = T + (CODD_I8_LAG ? 1 : 0);
         // one interval; IU (= t mod 3) picks the corpus ring slots statically.  EPI: a pending epilogue may run inside
         // (the generic loop); the tile-structured loop below runs it between intervals instead.
@@ -845,6 +935,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         }
 #endif
         if (pending) epilogue(p_u, p_ord);
+        }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (MODE == MODE_SAMPLE && pub_ord < my_tiles && tid < 256) {
             u64 key = lds_k[(kLists == 2 ? (pub_ord & 1) * 256 : 0) + tid];

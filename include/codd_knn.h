@@ -200,7 +200,7 @@ int codd_knn_ivf_search(codd_knn_index* index, const float* dev_queries, int B, 
  *            more elements take the second-generation int8 kernel, csrc/filter_i8.h; 1: only rows of
  *            more than 512 elements; 0: never), "i8v2_half" (1: batches of 65..128 queries take that kernel's
  *            8-query-block instantiation; 0: the first-generation kernel),
- *            "i8_pair" (1: that kernel synchronises once per two K-steps on rows of 768 / 1536 ... elements; 0: every
+ *            "i8_pair" (2: that kernel synchronises once per two K-steps on rows of 768 / 1536 ... elements, and rows of exactly 768 take its static form; 1: without the static form; 0: every
  *            K-step), "per_block" (7, bit mask: the int8 bound uses each 32-row block's own quantisation error instead of
  *            the corpus's worst — bit 0 in the tile kernel, bit 1 in finalize, bit 2 the block metadata by one LDS-DMA per
  *            tile; 0 = the device-wide bound everywhere), "fuse_fallback" (1: batches above 64 queries answer candidate-list

@@ -1,7 +1,7 @@
 // Development aid: compiles ONE instantiation of i8_tile_kernel (seconds instead of the library's minutes) so that its ISA and
 // resource usage can be read while the schedule is being edited:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -pragma-unroll-threshold=65536 -Icodd_query_engine_amd/csrc -Iinclude \
-//         -DONEK_MODE=0 -DONEK_S3=2 -DONEK_NQB=16 -DONEK_RES=false --cuda-device-only -S -o /tmp/onek/k.s scripts/dev/one_kernel.hip
+//         -DONEK_MODE=0 -DONEK_S3=3 -DONEK_NQB=16 -DONEK_RES=false --cuda-device-only -S -o /tmp/onek/k.s scripts/dev/one_kernel.hip
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #ifndef CODD_EXPERIMENTS
@@ -11,7 +11,7 @@
 #include "filter_i8.h"
 #ifndef ONEK_MODE
 #define ONEK_MODE 0
-#define ONEK_S3 2
+#define ONEK_S3 3
 #define ONEK_NQB 16
 #define ONEK_RES false
 #endif
