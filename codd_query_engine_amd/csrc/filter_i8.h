@@ -388,7 +388,8 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     auto epi_pair = [&](auto QB_, const EpiCtx& e) __attribute__((always_inline)) {
         constexpr int qb = decltype(QB_)::value;
         const i32x4 a0 = acc[0][qb], a1 = acc[1][qb];
-        const int m = max(max(max(a0[0], a0[1]), max(a0[2], a0[3])), max(max(a1[0], a1[1]), max(a1[2], a1[3])));
+        // (three v_max3 and one v_max: hipcc turns a balanced tree of two-operand max into five instructions)
+        const int m = max(max(max(max(max(a0[0], a0[1]), a0[2]), max(max(a0[3], a1[0]), a1[1])), a1[2]), a1[3]);
         // no accumulator of the pair reaches the threshold when the largest one does not (same scale, rounding is
         // monotone, a non-positive accumulator is below a positive threshold anyway).  The pre-test threshold is the exact one
         // rounded DOWN to bf16 (two per register: 16 of them cost 8 registers instead of 16 at the point where the program
