@@ -420,8 +420,27 @@ def main():
 
     launches_per_step = 4 * ((B + 255) // 256) + (B + 7) // 8  # upper bound on timed launches per step
     depth = args.pipeline if args.pipeline > 0 else (2 if searcher is not None else 1)
-    if searcher is None:
-        depth = 1
+
+    class _LocalAsync:
+        """One GPU, no process group: consecutive batches on `depth` alternating HIP streams (the index keeps one workspace per
+        stream), what ShardedSearcher.search_async does for the sharded path."""
+
+        def __init__(self, n):
+            self.streams = [torch.cuda.Stream(device=device) for _ in range(n)]
+            self.turn = 0
+
+        def search_async(self, q, kk, _depth):
+            side = self.streams[self.turn]
+            self.turn = (self.turn + 1) % len(self.streams)
+            side.wait_stream(torch.cuda.current_stream(device))
+            with torch.cuda.stream(side):
+                out = ix.search_tensors(q, kk)
+            q.record_stream(side)
+            from codd_query_engine_amd.sharded import PendingSearch
+
+            return PendingSearch(side, out)
+
+    apipe = searcher if searcher is not None else (_LocalAsync(depth) if depth > 1 else None)
     if depth == 1:
         # one stream: the HIP events around every heavy launch are taken inside the timed region itself
         ix.set_option("profile", args.steps * launches_per_step + 8)
@@ -437,12 +456,12 @@ def main():
         # the closing barrier returns.  Event pairs on concurrent streams would also time the wait for the other
         # stream's kernel, so the per-kernel durations come from K more steps on ONE stream right after.
         for _ in range(depth):
-            searcher.search_async(queries, k, depth).result()
+            apipe.search_async(queries, k, depth).result()
         barrier()
         t0 = time.perf_counter()
         pending = []
         for i in range(args.steps):
-            pending.append(searcher.search_async(batches[i % n_batches], k, depth))
+            pending.append(apipe.search_async(batches[i % n_batches], k, depth))
             if len(pending) >= depth:
                 pending.pop(0).result()
         for h in pending:
