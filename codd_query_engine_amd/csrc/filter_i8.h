@@ -67,6 +67,10 @@ constexpr int kBD = CODD_I8_BDEPTH;
 #define CODD_I8_SPREAD_VM 0           // pair program: 1 = the interval's vector-memory operations are issued one at a time behind MFMA groups instead of in a
                                       // block in front of them; 2 = ... the SIMD partners taking turns (waves 0..3 behind even groups, 4..7 behind odd ones)
 #endif
+#ifndef CODD_I8_EARLY_A
+#define CODD_I8_EARLY_A 3             // static six-step program, bit mask: the corpus loads of interval 2 (bit 0) / 4 (bit 1) go out in the tail of the odd interval
+                                      // in front of it, BEFORE the barrier (0: in the interval's own head, behind the barrier, with everything else)
+#endif
 #ifndef CODD_I8_FUSE_EPI
 #define CODD_I8_FUSE_EPI 0            // 1: the tile-structured filter program tests tile i's accumulators INSIDE the first K-step of tile i + 1 (epi_pair in front
                                       // of the MFMAs that restart the pair).  Built, bit-equal, measured 1.7-3 % SLOWER (profiles/r3/i8_tile_ablation.txt): the
@@ -623,10 +627,29 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             const char* A_cur = reinterpret_cast<const char*>(shadow8) + (int64_t)(u * tstride) * tile_bytes + wave * (6 * step_bytes);
             const int64_t dA = (int64_t)(G * tstride) * tile_bytes;
             unsigned px = 0u;                                         // 2 slots' bytes for odd tiles: slot ^ 2
+            // corpus loads "of interval I": step (I + 2) % 6 of this tile (I < 4) or the next one, into the ring slot interval I - 1 has
+            // just consumed.  Intervals 1 and 3 issue their own in their heads and those of the EVEN interval behind them in their
+            // tails, in front of their barriers (CODD_I8_EARLY_A): the heads of intervals 2 and 4 — which all eight waves run at the same
+            // moment, right behind the barrier — are left with the slice DMA only, and the loads go out while the SIMD partners are
+            // still staggered.  (Not interval 5 for the next tile's interval 0: the epilogue between them needs the third ring slot's
+            // registers — with all three slots in flight it spilled 16 registers to scratch.)
+            auto c_load = [&](auto I_, const char* A_next) __attribute__((always_inline)) {
+                constexpr int i = decltype(I_)::value % 6;
+                constexpr bool next_tile = decltype(I_)::value >= 4;
+                constexpr int li = ((i % 3) + 2) % 3;
+                constexpr int st = (i + 2) % 6;
+                const char* base = (next_tile ? A_next : A_cur) + st * step_bytes;
+                const i32x4 r = i8_rsrc(base, 4096);
+                i8_load_b128_nt<0>(ring[li][0], lane16, r);
+                i8_load_b128_nt<1024>(ring[li][1], lane16, r);
+                i8_load_b128_nt<2048>(ring[li][2], lane16, r);
+                i8_load_b128_nt<3072>(ring[li][3], lane16, r);
+            };
             auto s_interval = [&](auto I_, const char* A_next) __attribute__((always_inline)) {
                 constexpr int i = decltype(I_)::value;
-                constexpr int ci = i % 3, li = (ci + 2) % 3;
-                constexpr int st = (i + 2) % 6;                       // the step whose slice and corpus fragments are requested here
+                constexpr int ci = i % 3;
+                constexpr int st = (i + 2) % 6;                       // the step whose slice (and corpus fragments) are requested here
+                constexpr bool odd = (i & 1) != 0;
                 __builtin_amdgcn_sched_barrier(0);
                 const unsigned qaddr = lds0 + (((unsigned)((i & 3) * kSlotBytes)) ^ px) + (unsigned)lane16;
                 i32x4 b[kBD];
@@ -640,30 +663,56 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                     for (int j = 0; j < kDmaPerSlice; ++j) i8_dma_b128_s(dst + j * 8192, lane16, rsrc_q, wq + st * kI8SliceBytes + j * 8192);
                 }
 #endif
-                {
-                    const char* base = (i < 4 ? A_cur : A_next) + st * step_bytes;
-                    const i32x4 r = i8_rsrc(base, 4096);
-                    i8_load_b128_nt<0>(ring[li][0], lane16, r);
-                    i8_load_b128_nt<1024>(ring[li][1], lane16, r);
-                    i8_load_b128_nt<2048>(ring[li][2], lane16, r);
-                    i8_load_b128_nt<3072>(ring[li][3], lane16, r);
-                }
-                // the corpus step requested two intervals ago: younger are the previous interval's operations and this one's
-                i8_wait_vm<(i == 0 ? kOpsN + kOps0 : (i == 1 ? kOps0 + kOpsN : 2 * kOpsN))>(ring[ci][0], ring[ci][1], ring[ci][2], ring[ci][3]);
+                constexpr bool e2 = (CODD_I8_EARLY_A & 1) != 0, e4 = (CODD_I8_EARLY_A & 2) != 0;
+                constexpr bool early_here = (i == 2 && e2) || (i == 4 && e4);   // this interval's loads went out in the tail of the one before
+                constexpr bool early_next = (i == 1 && e2) || (i == 3 && e4);   // ... and the next one's go out in this one's tail
+                if constexpr (!early_here) c_load(I_, A_next);
+                // the corpus step requested two intervals ago; younger in the queue (issue order, kD = kDmaPerSlice, rs = the block
+                // metadata DMA of interval 0):
+                // (counted by walking the tile's issue order backwards from this interval's last operation to the loads of interval i - 2:
+                //  head(j) = [rs (j == 0)] [kD slice DMA] [4 corpus loads unless early], tail(j) = [4: the early loads of j + 1])
+                constexpr int kYounger = [&]() constexpr {
+                    auto early = [&](int j) constexpr { return (j == 2 && e2) || (j == 4 && e4); };
+                    int n = 0;
+                    // this interval's head, then backwards over tail(i-1), head(i-1), tail(i-2), head(i-2) until the loads of i - 2 are reached
+                    n += (i == 0 ? 1 : 0) + kDmaPerSlice + (early(i) ? 0 : 4);
+                    const int j1 = (i + 5) % 6, j2 = (i + 4) % 6;
+                    if (early(i)) n += 4;                                   // tail(i-1): this interval's own early loads
+                    n += (j1 == 0 ? 1 : 0) + kDmaPerSlice + (early(j1) ? 0 : 4);   // head(i-1)
+                    if (early(j1)) n += 4;                                  // tail(i-2): the early loads of i - 1
+                    if (early(j2)) {
+                        // the loads of i - 2 sit in tail(i-3): behind them the whole head(i-2)
+                        n += (j2 == 0 ? 1 : 0) + kDmaPerSlice;
+                    }
+                    return n;
+                }();
+                i8_wait_vm<kYounger>(ring[ci][0], ring[ci][1], ring[ci][2], ring[ci][3]);
                 __builtin_amdgcn_sched_barrier(0);
                 if (!CODD_I8_EARLY_FRAGS) frag_prefetch(b, qaddr);
                 mfma_step(std::integral_constant<int, ci>{}, std::integral_constant<bool, i == 0>{}, std::false_type{}, b, qaddr, nullptr, [](auto) {});
-                if constexpr (i & 1) {
+                if constexpr (odd) {
+                    if constexpr (early_next) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        c_load(std::integral_constant<int, i + 1>{}, A_next);
+                    }
                     // the slices of steps t + 1 and t + 2 (and, i == 1, the tile's block metadata) have landed: younger than this
-                    // interval's slice DMA are only its corpus loads
-                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(kAPerIv) : "memory");
+                    // interval's slice DMA are only its corpus loads (and the next interval's, issued early)
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(early_next ? 2 * kAPerIv : kAPerIv) : "memory");
                 }
             };
             for (int o = 0; o < my_tiles; ++o) {
                 const char* A_next = o + 1 < my_tiles ? A_cur + dA : A_cur;   // (past the last tile the loads stay on it: unconditional, never consumed)
                 s_interval(std::integral_constant<int, 0>{}, A_next);
                 s_interval(std::integral_constant<int, 1>{}, A_next);
-                // behind the barrier of the tile's second interval every wave has folded the previous tile: its hit count is stable
+                s_interval(std::integral_constant<int, 2>{}, A_next);
+                s_interval(std::integral_constant<int, 3>{}, A_next);
+                s_interval(std::integral_constant<int, 4>{}, A_next);
+                s_interval(std::integral_constant<int, 5>{}, A_next);
+                // The workgroup's hit list is flushed HERE when it runs full: behind the tile's last barrier (three barriers after the
+                // previous tile's epilogue: every wave's appends are in, the count is stable) and in front of this tile's epilogue — the one
+                // point of the tile where only two of the three ring slots are in flight, so the flush code finds its registers (behind the
+                // barrier of interval 1, with interval 2's loads issued early, it spilled 9 of them).  The rare branch ends in its own
+                // barrier: the counter is back at 0 before any wave appends again.
                 if (o >= 1) {
                     const unsigned cnt = lds_w[256];
                     if (cnt > (unsigned)(CODD_FLUSH_AT)) {
@@ -672,12 +721,9 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                         flush_hits_binned(lds_hits, cnt < kListCap ? cnt : kListCap, tid_f, lds_w + 832, hits, hit_cnt, cap_q, reinterpret_cast<const float*>(lds_w + 320));
                         __syncthreads();
                         if (tid == 0) lds_w[256] = 0u;
+                        __syncthreads();
                     }
                 }
-                s_interval(std::integral_constant<int, 2>{}, A_next);
-                s_interval(std::integral_constant<int, 3>{}, A_next);
-                s_interval(std::integral_constant<int, 4>{}, A_next);
-                s_interval(std::integral_constant<int, 5>{}, A_next);
                 epilogue(u, (int)(px != 0u));
                 u += G;
                 A_cur = A_next;
