@@ -1246,7 +1246,8 @@ struct codd_knn_index : WorkBufs {
     int i8_pair = 2;              // rows of 6, 12, ... K-steps: the staged tile program with one workgroup barrier per two K-steps ("i8_pair" option: 0 = one per K-step;
                                   // 2 = ... and rows of exactly 6 K-steps its static form, i8_tile_kernel<., 3, ., false>)
     int sample_div8 = 28;         // its thresholds come from a larger sample (the int8 slack is ~5x the bf16 one)
-    int sample_rounds8 = 3;       // ... of at least this many rounds of workgroups (one tile each) when the batch has more than 32 queries
+    int sample_rounds8 = 2;       // ... of at least this many rounds of workgroups (one tile each) when the batch has more than 32 queries (3 until the round-3 epilogue:
+                                  // at 1.25M rows two rounds trade 13 us of sample for 7 us of filter, gpurun_out/r3n/ab_sample_1p25m.txt)
     uint4* shadow8 = nullptr;
     int64_t shadow8_rows = 0;     // rows the allocation covers (multiple of 256)
     float* rscale = nullptr;      // [shadow8_rows]
@@ -1689,9 +1690,9 @@ int ensure_filter_workspace(codd_knn_index* ix) {
 int64_t sample_tile_count(const codd_knn_index* ix, int64_t ntiles, int k, bool use8 = false, int nbq = 8) {
     int64_t ts = ntiles / (use8 ? (nbq == 1 ? 2 * ix->sample_div8 : ix->sample_div8) : ix->sample_div);
     if (use8) {
-        // the int8 filter pays more per hit (wider slack, more of them) and less per sampled tile: three rounds of
-        // workgroups where that is still under a quarter of the corpus (scripts/int8_sweep.py: 1/6 of a 1.25M-row
-        // shard, 1/20 of 10M rows; twice as sparse for <= 32 queries, whose sample is a pure byte stream)
+        // the int8 filter pays more per hit (wider slack, more of them) and less per sampled tile: "sample_rounds8" rounds of
+        // workgroups (2 since round 3's cheaper epilogue; 3 before) where that is still under a quarter of the corpus
+        // (1/10 of a 1.25M-row shard, 1/28 of 10M rows; twice as sparse for <= 32 queries, whose sample is a pure byte stream)
         const int64_t rounds = (nbq == 1 ? 1 : ix->sample_rounds8) * (int64_t)ix->num_cus;
         const int64_t floor8 = rounds < ntiles / 4 ? rounds : ntiles / 4;
         if (ts < floor8) ts = floor8;

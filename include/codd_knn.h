@@ -193,7 +193,7 @@ int codd_knn_ivf_search(codd_knn_index* index, const float* dev_queries, int B, 
  *            "shadow8_max_surv" (4000) survivors per query or send queries to the fallback: dense
  *            clusters — unless the 2-byte passes are seen to leave at least half as many), "sample_div8" (28:
  *            the int8 filter's thresholds come from a sample of 1/28 of the row tiles) and
- *            "sample_rounds8" (3: ... of at least that many tiles per compute unit for batches of
+ *            "sample_rounds8" (2: ... of at least that many tiles per compute unit for batches of
  *            more than 32 queries, up to a quarter of the corpus; performance only),
  *            "resident_q" (1: rows of <= 512 int8 elements keep the query block in LDS for the
  *            whole launch), "i8v2" (2: batches of 65..256 queries on rows of 384 or

@@ -71,6 +71,64 @@ def test_tile_kernel_is_exact(Index, n, d, B, k, dtype, i8v2):
     ix.close()
 
 
+@pytest.mark.parametrize(
+    "n,d,B,pair",
+    [
+        (70_001, 768, 256, 2),    # the static six-step program (the default for 768 elements)
+        (70_001, 768, 256, 1),    # the same rows through the pair program with run-time cursors
+        (70_001, 768, 256, 0),    # ... and with a barrier behind every K-step
+        (70_001, 768, 100, 2),    # 8 query blocks, static
+        (70_001, 768, 100, 1),
+        (40_000, 1536, 256, 2),   # 12 K-steps: the pair program's inner loop (no static form)
+        (40_000, 1536, 128, 2),
+        (5_000, 768, 256, 2),     # 20 tiles: most workgroups have none, the others exactly one (the static loop's first tile is its last)
+        (131_072 + 300, 768, 200, 2),  # two and three tiles per workgroup, a ragged last one
+    ],
+)
+def test_every_tile_program_is_exact(Index, n, d, B, pair):
+    """"i8_pair" picks the tile program: 2 = the static six-step program where rows have exactly 6 K-steps (round 3: every cursor a
+    compile-time constant, early corpus loads, the flush at the end of the tile), 1 = the pair program with run-time cursors, 0 = one
+    barrier per K-step.  All of them must return the oracle's bits, whichever the default happens to be."""
+    rng = np.random.default_rng(n + B + d + pair)
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((B, d)).astype(np.float32)
+    q[5] = raw[n - 1] + 0.05 * rng.standard_normal(d).astype(np.float32)   # a neighbour in the ragged last tile
+    q[6] = raw[0]
+    dtype = "f32" if d <= 1024 else "bf16"   # (f32 rows stop at 1,024 elements)
+    ix = build(Index, raw, dtype, 1)
+    ix.set_option("i8_pair", pair)
+    k = 10
+    for rep in range(2):
+        dist, rows = ix.search(q, k)
+        d_ref, i_ref = oracle_answer(raw, q, k, dtype)
+        assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref), rep
+    assert ix.stat("i8v2_passes") == 2 and ix.stat("fallback_queries") == 0
+    ix.close()
+
+
+def test_static_program_flushes_a_full_hit_list_at_the_end_of_a_tile(Index):
+    """A cluster spread over many tiles that 200 queries point at: the workgroup's LDS hit list passes its flush mark in the
+    middle of the launch, so the static program's flush (behind the tile's last barrier, in front of its epilogue, with its own
+    closing barrier) runs many times; the candidates it hands over must be complete."""
+    rng = np.random.default_rng(314)
+    n, d, B, k = 200_000, 768, 256, 10
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    centre = rng.standard_normal(d).astype(np.float32)
+    centre /= np.linalg.norm(centre)
+    members = rng.choice(n, size=30_000, replace=False)
+    raw[members] = centre + 0.12 * rng.standard_normal((30_000, d)).astype(np.float32) / np.sqrt(d)
+    q = rng.standard_normal((B, d)).astype(np.float32)
+    q[:200] = centre + 0.12 * rng.standard_normal((200, d)).astype(np.float32) / np.sqrt(d)
+    ix = build(Index, raw)
+    ix.set_option("shadow8_cooldown", 0)
+    dist, rows = ix.search(q, k)
+    assert ix.stat("i8v2_passes") == 1
+    d_ref, i_ref = oracle_answer(raw, q, k, "f32")
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    assert ix.stat("filter_hits") >= 200 * 25_000
+    ix.close()
+
+
 def test_tile_kernel_writes_the_same_candidate_lists_as_the_first_generation(Index):
     """Same sample, same anchors: the results must not depend on which kernel ran.  Since round 3 the tile kernel evaluates the
     int8 bound per 32-row block (each block's own quantisation error norm instead of the corpus's worst), so its candidate list
