@@ -689,6 +689,9 @@ __global__ __launch_bounds__(256) void prep_queries8_kernel(const float* __restr
 //     1.001 eps_r + 2e-6 as the int8 filter's (device-wide eps_r).
 // Results are bit-identical to every other path: the survivors' scores are the canonical ones.
 // ---------------------------------------------------------------------------------------------------------------
+#if !CODD_EXPERIMENTS && (defined(CODD_SB_EXP_NOOFFER) || defined(CODD_SB_EXP_NOSTREAM) || defined(CODD_SB_EXP_NOFINAL))
+#error "the CODD_SB_EXP_* switches return wrong results: they exist only in -DCODD_EXPERIMENTS=1 builds (build_variant)"
+#endif
 constexpr int kSbKeep = 8;        // keys a wave publishes
 constexpr int kSbThreads = kFinThreads;
 static_assert(kSbThreads == 512, "finalize_body's workgroup");
@@ -787,8 +790,15 @@ __global__ __launch_bounds__(kSbThreads) void small_batch_kernel(const uint4* __
         const int64_t row = (block << 5) + 16 * (uu & 1) + r;
         const float score = (float)acc * scale * qscale;
         const u64 key = (lane < 16 && row < n) ? make_key(score, (uint32_t)row) : 0ull;
+#ifdef CODD_SB_EXP_NOOFFER
+        asm volatile("" ::"v"(key));  // diagnostic: scores computed, no top-k insert
+#else
         L.offer_lanes(key, kWave, lane);
+#endif
     };
+#ifdef CODD_SB_EXP_NOSTREAM
+    u = nunits;  // diagnostic: no stream at all
+#endif
     while (u < nunits) {
         load_unit(cb, sb, u + W);
         score_unit(ca, sa, u);
@@ -811,6 +821,10 @@ __global__ __launch_bounds__(kSbThreads) void small_batch_kernel(const uint4* __
     __syncthreads();
     if (!s_last) return;
     __threadfence();
+#ifdef CODD_SB_EXP_NOFINAL
+    if (tid == 0) { *ticket = 0u; *fb_count = 0u; }
+    return;  // diagnostic: nothing behind the arrival ticket (results are garbage)
+#endif
     if (tid == 0) {
         *ticket = 0u;    // (the next search finds the ticket at zero: no clearing launch)
         *fb_count = 0u;  // (the fallback queue of THIS search starts empty; the scan behind this kernel reads it)
