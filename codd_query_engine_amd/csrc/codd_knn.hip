@@ -2390,7 +2390,7 @@ int search_impl(codd_knn_index* ix, const float* dev_queries, int B, int k, uint
 extern "C" {
 
 const char* codd_knn_version(void) {
-    return "codd_knn 0.5.0 gfx950"
+    return "codd_knn 0.6.0 gfx950"
 #if CODD_SHADOW_F16
            " shadow=f16"
 #else

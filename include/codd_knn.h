@@ -202,8 +202,8 @@ int codd_knn_ivf_search(codd_knn_index* index, const float* dev_queries, int B, 
  *            8-query-block instantiation; 0: the first-generation kernel),
  *            "i8_pair" (2: that kernel synchronises once per two K-steps on rows of 768 / 1536 ... elements, and rows of exactly 768 take its static form; 1: without the static form; 0: every
  *            K-step), "per_block" (7, bit mask: the int8 bound uses each 32-row block's own quantisation error instead of
- *            the corpus's worst — bit 0 in the tile kernel, bit 1 in finalize, bit 2 the block metadata by one LDS-DMA per
- *            tile; 0 = the device-wide bound everywhere), "fuse_fallback" (1: batches above 64 queries answer candidate-list
+ *            the corpus's worst — bit 0 in the tile kernel, bit 1 in finalize (bit 2 is accepted and ignored: the
+ *            tile kernel's filter pass always fetches the block metadata by one LDS-DMA per tile); 0 = the device-wide bound everywhere), "fuse_fallback" (1: batches above 64 queries answer candidate-list
  *            overflows inside the finalize launch; 0: a launch of their own), "small_batch_max" (0; 1: a single query on
  *            <= 2M-row int8 shadows is answered by ONE launch — measured slower than the three-launch chain, see
  *            DESIGN.md §12, hence off), "ivf_share" (1: codd_knn_ivf_search scans a probed list once for all queries of the
