@@ -1687,6 +1687,7 @@ int ensure_filter_workspace(codd_knn_index* ix) {
             HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)filter_lds_bytes(MODE_FILTER)));
         const void* tile_fns[] = {(const void*)&i8_tile_kernel<MODE_FILTER, 0>, (const void*)&i8_tile_kernel<MODE_FILTER, 1>, (const void*)&i8_tile_kernel<MODE_FILTER, 2>,
                                   (const void*)&i8_tile_kernel<MODE_FILTER, 0, 8>, (const void*)&i8_tile_kernel<MODE_FILTER, 1, 8>, (const void*)&i8_tile_kernel<MODE_FILTER, 2, 8>,
+                                  (const void*)&i8_tile_kernel<MODE_FILTER, 3>, (const void*)&i8_tile_kernel<MODE_FILTER, 3, 8>,
                                   (const void*)&i8_tile_kernel<MODE_FILTER, 1, 16, true>, (const void*)&i8_tile_kernel<MODE_FILTER, 0, 16, true>,
                                   (const void*)&i8_tile_kernel<MODE_FILTER, 1, 8, true>, (const void*)&i8_tile_kernel<MODE_FILTER, 0, 8, true>};
         for (const void* fn : tile_fns) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_FILTER)));
@@ -1923,7 +1924,8 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     hipLaunchKernelGGL((gemm_filter_kernel<MODE_SAMPLE, NBQ, 1, 2>), g, b, lds, st, shadow, qfrag, n, nsteps, ts, stride, \
                        nullptr, ix->bucket_max, nullptr, nullptr, 0, nullptr, nullptr, ix->rscale, ix->qmeta)
         if (tile_v2) {
-            // (the sample pass keeps the generic program: its tile-structured instantiation spills inside the loop)
+            // (the sample pass keeps the generic program: its tile-structured instantiations — the static six-step one too, tried in round 3 —
+            //  spill inside the loop: the fold's registers on top of two corpus ring slots in flight)
 #define CODD_LAUNCH_TILE8_SAMPLE(NQB, RES)                                                                                                    \
     hipLaunchKernelGGL((i8_tile_kernel<MODE_SAMPLE, 0, NQB, RES>), g, b, i8_lds_bytes(MODE_SAMPLE), st, shadow, qfrag, n, nsteps, ts, stride, \
                        nullptr, ix->bucket_max, nullptr, nullptr, 0, nullptr, ix->rscale, ix->qmeta)
