@@ -1271,7 +1271,9 @@ struct codd_knn_index : WorkBufs {
     int64_t dirty_lo = 0, dirty_hi = 0;  // rows written since the int8 shadow was last brought up to date: [lo, hi)
     hipStream_t shadow8_stream = nullptr;  // the stream the last rebuild ran on, and its completion
     hipEvent_t shadow8_ready = nullptr;
-    int64_t stat_shadow8_builds = 0, stat_shadow8_passes = 0, stat_i8v2_passes = 0;
+    int64_t stat_shadow8_builds = 0, stat_shadow8_passes = 0, stat_i8v2_passes = 0, stat_f16_tile_passes = 0;
+    int f16_tile = 1;             // the 2-byte filter of 129..256 queries over rows of 6, 12, ... 64-element K-steps (768 elements: 12) runs the tile program of
+                                  // filter_i8.h on fp16 operands ("f16_tile" option; 0 = gemm_filter_kernel)
     // the worst row's quantisation error, copied back asynchronously after every build: a corpus with badly
     // quantisable rows (one large element, many small ones) would make the int8 bound useless and send every small batch
     // to the exact-scan fallback, so such an index keeps the bf16 filter.  Performance only: never needed for exactness.
@@ -1688,6 +1690,7 @@ int ensure_filter_workspace(codd_knn_index* ix) {
         const void* tile_fns[] = {(const void*)&i8_tile_kernel<MODE_FILTER, 0>, (const void*)&i8_tile_kernel<MODE_FILTER, 1>, (const void*)&i8_tile_kernel<MODE_FILTER, 2>,
                                   (const void*)&i8_tile_kernel<MODE_FILTER, 0, 8>, (const void*)&i8_tile_kernel<MODE_FILTER, 1, 8>, (const void*)&i8_tile_kernel<MODE_FILTER, 2, 8>,
                                   (const void*)&i8_tile_kernel<MODE_FILTER, 3>, (const void*)&i8_tile_kernel<MODE_FILTER, 3, 8>,
+                                  (const void*)&i8_tile_kernel<MODE_FILTER, 2, 16, false, true>,
                                   (const void*)&i8_tile_kernel<MODE_FILTER, 1, 16, true>, (const void*)&i8_tile_kernel<MODE_FILTER, 0, 16, true>,
                                   (const void*)&i8_tile_kernel<MODE_FILTER, 1, 8, true>, (const void*)&i8_tile_kernel<MODE_FILTER, 0, 8, true>};
         for (const void* fn : tile_fns) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_FILTER)));
@@ -1905,6 +1908,9 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
     // full query blocks: the second-generation int8 kernel (filter_i8.h); rows whose query block fits the LDS keep the resident one
     const bool tile_v2 = use8 && (nbq == 8 || (nbq == 4 && ix->i8v2_half)) && ((ix->i8v2 == 1 && !resident && nsteps >= 3) || (ix->i8v2 == 2 && nsteps >= 3));
     if (tile_v2) ix->stat_i8v2_passes++;
+    // the 2-byte filter (dense clusters the int8 slack cannot separate, the int8 filter switched off): the same tile program on fp16 operands
+    const bool tile_f16 = CODD_SHADOW_F16 && CODD_MFMA16 && !use8 && nbq == 8 && nsteps % 6 == 0 && ix->f16_tile;
+    if (tile_f16) ix->stat_f16_tile_passes++;
     const int64_t ts = sample_tile_count(ix, ntiles, k, use8, nbq);
     const int64_t stride = ntiles / ts;
     {
@@ -2004,7 +2010,11 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
 #define CODD_LAUNCH_FILTER8P(NBQ)                                                                                           \
     hipLaunchKernelGGL((gemm_filter_kernel<MODE_FILTER, NBQ, 1, 2>), g, b, lds, st, shadow, qfrag, n, nsteps, ntiles, \
                        (int64_t)1, ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, nullptr, ix->rscale, ix->qmeta)
-        if (tile_v2) {
+        if (tile_f16) {
+            // (thr doubles as the 256 readable bytes the kernel's per-tile metadata request needs; fp16 operands carry no scales)
+            hipLaunchKernelGGL((i8_tile_kernel<MODE_FILTER, 2, 16, false, true>), g, b, i8_lds_bytes(MODE_FILTER), st, shadow, qfrag, n, nsteps, ntiles, (int64_t)1,
+                               ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, nullptr, nullptr, reinterpret_cast<const float2*>(ix->thr), 0.0f);
+        } else if (tile_v2) {
 #ifdef CODD_I8_EXP_STAMPS  // (diagnostic build: the filter pass writes its per-wave phase stamps over the sample's bucket keys, which anchor_thr has consumed)
 #define CODD_STAMP_BUF ix->bucket_max
 #else
@@ -2954,6 +2964,11 @@ int codd_knn_set_option(codd_knn_index* ix, const char* key, int64_t value) {
         ix->i8v2 = (int)value;
         return CODD_KNN_OK;
     }
+    if (strcmp(key, "f16_tile") == 0) {
+        if (value != 0 && value != 1) return fail(CODD_KNN_EINVAL, "f16_tile must be 0 or 1%s");
+        ix->f16_tile = (int)value;
+        return CODD_KNN_OK;
+    }
     if (strcmp(key, "ivf_share") == 0) {
         if (value != 0 && value != 1) return fail(CODD_KNN_EINVAL, "ivf_share must be 0 or 1%s");
         ix->ivf_share = (int)value;
@@ -3067,6 +3082,7 @@ int codd_knn_get_stat(const codd_knn_index* ix, const char* key, int64_t* out) {
     else if (strcmp(key, "all_normalized") == 0) *out = ix->all_normalized ? 1 : 0;
     else if (strcmp(key, "shadow8_passes") == 0) *out = ix->stat_shadow8_passes;
     else if (strcmp(key, "i8v2_passes") == 0) *out = ix->stat_i8v2_passes;
+    else if (strcmp(key, "f16_tile_passes") == 0) *out = ix->stat_f16_tile_passes;
     else if (strcmp(key, "small_batch_passes") == 0) *out = ix->stat_small_batch;
     else if (strcmp(key, "shadow8_cooldowns") == 0) *out = ix->stat_cooldowns;
     else if (strcmp(key, "shadow8_wide_blocks") == 0) {  // blocks whose error norm exceeds shadow8_max_eps, as last read back

@@ -171,7 +171,12 @@ __host__ __device__ constexpr size_t i8_lds_bytes(int mode) {
 // program with ONE workgroup barrier per TWO K-steps.  The four LDS slices hold the two slices being read and the two
 // landing; the barrier behind every odd K-step hands both pairs over at once (the barrier behind an even K-step protected
 // nothing that the next one does not: slot (t + 2) & 3, requested during step t, was last read during step t - 2).
-template <int MODE, int TS, int NQB = 16, bool RES = false>
+// F16 (round 3): the same program over the 2-BYTE shadow (fp16; filter_gemm.h: identical piece order, a 128-byte K-step is 64 elements, two
+// v_mfma_f32_16x16x32_f16 per block pair instead of two v_mfma_i32_16x16x64_i8 — byte for byte the same operand traffic and the same matrix time per
+// byte).  The accumulators ARE the approximate scores (no scales, no quantisation error: the bound lives in thr[q] = L - eps, anchor_thr_kernel),
+// `thr` holds one threshold per query, `bmeta` only has to be 256 readable bytes (the per-tile metadata DMA is kept so that the counted waits stay the
+// same: what it fetches is never read), `rscale` and `qscale` are not read.  Filter pass only (the sample pass of the 2-byte filter stays gemm_filter_kernel's).
+template <int MODE, int TS, int NQB = 16, bool RES = false, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict__ shadow8, const uint4* __restrict__ qfrag8, int64_t n, int nsteps,
                                                          int64_t ntiles_run, int64_t tile_stride, const float* __restrict__ thr,
                                                          u64* __restrict__ bucket_key, u64* __restrict__ hits, unsigned* __restrict__ hit_cnt,
@@ -192,6 +197,8 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     static_assert(TS >= 0 && TS <= 3 && !(kPair && (RES || CODD_I8_LAG)), "pair barriers: staged tile-structured program only");
     static_assert(!kStatic6 || (MODE == MODE_FILTER && !CODD_I8_FUSE_EPI && !CODD_I8_SPREAD_VM), "the static six-step program: filter pass, standalone epilogue");
     static_assert(NQB == 16 || NQB == 8, "256 or 128 queries");
+    static_assert(!F16 || (MODE == MODE_FILTER && !RES), "fp16 operands: the staged filter pass only");
+    typedef std::conditional_t<F16, f32x4, i32x4> acc4_t;
     constexpr int kDmaPerSlice = NQB / 4;                 // this wave's 1 KiB chunks of a slice
     constexpr int kDmaPerIv = RES ? 0 : kDmaPerSlice;     // slice DMA per interval
     constexpr int kOpsPerIv = 1 + kDmaPerIv + kAPerIv;    // vector-memory operations per interval (see above)
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
 
     if (MODE == MODE_FILTER) {
         if (tid < 256) {
-            const float th = thr[tid] / qscale[tid];  // the test runs on acc * rscale[row]
+            const float th = F16 ? thr[tid] : thr[tid] / qscale[F16 ? 0 : tid];  // the test runs on acc * rscale[row] (fp16: on the accumulator itself)
             // the pre-test (largest accumulator of a block pair x the block's scale) is only conclusive for a positive
             // threshold: thresholds <= 0 (and NaN: a zero query) always take the exact per-value test.  Stored rounded DOWN to
             // bf16 (truncation of a positive float; -inf and +inf are exact), query q = 16 qb + c in half (qb & 1) of word
@@ -242,11 +249,11 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             const int qb = tid >> 4, c = tid & 15, j = qb >> 1;
             reinterpret_cast<unsigned short*>(lds_w)[2 * (((j >> 2) * 16 + c) * 4 + (j & 3)) + (qb & 1)] = (unsigned short)(__float_as_uint(pre) >> 16);
             lds_w[576 + tid] = __float_as_uint(th);
-            lds_w[320 + tid] = __float_as_uint(qscale[tid]);
+            lds_w[320 + tid] = __float_as_uint(F16 ? 1.0f : qscale[F16 ? 0 : tid]);
             // u_q (0 for padding and zero queries: their scale is 0) and the workgroup's maximum of it, per wave here, folded
             // behind the prologue's barrier
-            const float qs = qscale[tid];
-            const float u = qs > 0.0f ? qscale[768 + tid] / qs : 0.0f;
+            const float qs = F16 ? 1.0f : qscale[F16 ? 0 : tid];
+            const float u = (!F16 && qs > 0.0f) ? qscale[F16 ? 0 : 768 + tid] / qs : 0.0f;
             lds_w[1088 + tid] = __float_as_uint(u);
             const float um = i8_wave_max(u);
             if (lane == 0) lds_w[260 + wave] = __float_as_uint(um);
@@ -265,11 +272,11 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     const int tile_bytes = 8 * nsteps * step_bytes;
 
     float u_max = 0.0f;  // FILTER: max over the batch of B(q) / qscale_q (uniform; set behind the prologue's barrier)
-    i32x4 acc[2][NQB];
+    acc4_t acc[2][NQB];
 #pragma unroll
     for (int rs = 0; rs < 2; ++rs)
 #pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) acc[rs][qb] = i32x4{0, 0, 0, 0};
+        for (int qb = 0; qb < NQB; ++qb) acc[rs][qb] = acc4_t{0, 0, 0, 0};
 
     // ---- corpus fragments: HBM -> registers, ring of 3 K-steps, the cursor runs 2 steps ahead (1 for a lagging wave) ----
     int l_u = first_u;  // run-tile ordinal of the next step to load
@@ -336,8 +343,9 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         if constexpr (MODE == MODE_FILTER) {
             // the tile's eight blocks' {scale, error norm}: dwords [2 w], [2 w + 1] of the buffer belong to wave w (one 256-byte DMA:
             // 32 blocks from the tile's first one — the allocation has the head room; every wave writes the same bytes)
-            const unsigned blk0 = (unsigned)(u * tstride) * (unsigned)(kTileRows / 32);
-            const unsigned nblk = (n_rows + 31u) / 32u;
+            // (fp16 operands: no scales — the same 256 bytes every time, never read; the request keeps the operation count)
+            const unsigned blk0 = F16 ? 0u : (unsigned)(u * tstride) * (unsigned)(kTileRows / 32);
+            const unsigned nblk = F16 ? 1u : (n_rows + 31u) / 32u;
             i8_dma_b32(lds0 + (unsigned)(4 * kI8SliceBytes + kI8Words * 4 + ((ord & 1) * kI8RsStride) * 4), lane4,
                        i8_rsrc(bmeta + (blk0 < nblk ? blk0 : 0), blk0 < nblk ? 256u : 0u), 0);
         } else {
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
         // ONE scale per 32-row block (shadow8_from_rows_kernel), so the wave's rows share it and the pre-test on a pair's
         // largest accumulator is EXACT at pair level: it passes iff some value of the pair passes.  Rows past the count
         // carry NaN: the block's first row exists whenever any of its rows does, and the per-value test masks the others.
-        const float rs0 = lds_rs[(ord & 1) * kI8RsStride + 2 * wave], eb0 = lds_rs[(ord & 1) * kI8RsStride + 2 * wave + 1];
+        const float rs0 = F16 ? 1.0f : lds_rs[(ord & 1) * kI8RsStride + 2 * wave], eb0 = F16 ? 0.0f : lds_rs[(ord & 1) * kI8RsStride + 2 * wave + 1];
         e.rsl = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(valid ? rs0 : __builtin_nanf(""))));
         e.inv_rsl = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(1.0f / (valid ? rs0 : __builtin_nanf("")))));
         e.eb = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(eb0))) * eb_scale;  // (eb_scale 0: the device-wide bound, thr = L - eps(q))
@@ -391,16 +399,20 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     };
     auto epi_pair = [&](auto QB_, const EpiCtx& e) __attribute__((always_inline)) {
         constexpr int qb = decltype(QB_)::value;
-        const i32x4 a0 = acc[0][qb], a1 = acc[1][qb];
+        const acc4_t a0 = acc[0][qb], a1 = acc[1][qb];
         // (three v_max3 and one v_max: hipcc turns a balanced tree of two-operand max into five instructions)
-        const int m = max(max(max(max(max(a0[0], a0[1]), a0[2]), max(max(a0[3], a1[0]), a1[1])), a1[2]), a1[3]);
+        auto mx = [](auto x, auto y) __attribute__((always_inline)) { return x > y ? x : y; };   // (no NaN among finite products of finite operands)
+        const auto m = mx(mx(mx(mx(mx(a0[0], a0[1]), a0[2]), mx(mx(a0[3], a1[0]), a1[1])), a1[2]), a1[3]);
         // no accumulator of the pair reaches the threshold when the largest one does not (same scale, rounding is
         // monotone, a non-positive accumulator is below a positive threshold anyway).  The pre-test threshold is the exact one
         // rounded DOWN to bf16 (two per register: 16 of them cost 8 registers instead of 16 at the point where the program
         // is tightest); the per-value test below uses the exact one.
         const unsigned w = e.thw[qb >> 3][(qb >> 1) & 3];
         const float thp = __uint_as_float((qb & 1) ? (w & 0xffff0000u) : (w << 16));
-        if (__builtin_expect(__any(__builtin_fmaf((float)m, e.rsl, e.ueb) >= thp), 0)) {
+        bool pass;
+        if constexpr (F16) pass = (float)m >= thp;   // the accumulator IS the approximate score
+        else pass = __builtin_fmaf((float)m, e.rsl, e.ueb) >= thp;
+        if (__builtin_expect(__any(pass), 0)) {
             int l = lane;
             asm volatile("" : "+v"(l));  // (lane coordinates derived BEHIND the opaque asm: hipcc otherwise computes them once at kernel start and parks them in scratch)
             const int c = l & 15, lg = l >> 4;
@@ -435,17 +447,27 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             // added (the hit list may hold extra rows, never miss one).  One compare per value instead of convert + multiply +
             // compare: the eight waves of a workgroup are all in their epilogues at once, so its instruction count is wall time.
             // NaN threshold (a zero query): nothing passes, as with the float compare.  Rows past the count: masked in the last tile.
-            const float x = th * e.inv_rsl;
-            int T = x >= 2.0e9f ? INT_MAX : (x <= -2.0e9f ? INT_MIN + 1 : (int)x - 2);
-            if (!(th == th)) T = INT_MAX;
-            int av[8];
+            typedef std::conditional_t<F16, float, int> val_t;
+            val_t T;      // a value is a hit iff it is >= T
+            val_t kMasked;
+            if constexpr (F16) {
+                T = th;   // (NaN: no comparison holds)
+                kMasked = -INFINITY;
+            } else {
+                const float x = th * e.inv_rsl;
+                T = x >= 2.0e9f ? INT_MAX : (x <= -2.0e9f ? INT_MIN + 1 : (int)x - 2);
+                if (!(th == th)) T = INT_MAX;
+                kMasked = INT_MIN;
+            }
+            val_t av[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) av[i] = i < 4 ? a0[i] : a1[i - 4];
             if (e.wrow0 + 32u > n_rows) {  // (uniform: the corpus's last 32-row block only)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) av[i] = row0 + (unsigned)(16 * (i >> 2) + (i & 3)) < n_rows ? av[i] : INT_MIN;
+                for (int i = 0; i < 8; ++i) av[i] = row0 + (unsigned)(16 * (i >> 2) + (i & 3)) < n_rows ? av[i] : kMasked;
             }
-            int sa = 0, si = -1, cnt = 0;
+            val_t sa = 0;
+            int si = -1, cnt = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const bool h = av[i] >= T;
@@ -453,14 +475,14 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                 si = h ? i : si;
                 cnt += h ? 1 : 0;
             }
-            const float sv = (float)sa * e.rsl;  // the first-generation kernel's expression (its rscale[row] IS the block's scale)
+            const float sv = F16 ? (float)sa : (float)sa * e.rsl;  // the first-generation kernel's expression (its rscale[row] IS the block's scale)
 #ifdef CODD_I8_EXP_NOAPPEND
             asm volatile("" ::"v"(sv), "v"(si), "v"(cnt));  // diagnostic: the per-value test runs, nothing is appended
 #else
             if (__builtin_expect(__any(cnt > 1), 0)) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
-                    if (av[i] >= T) append((float)av[i] * e.rsl, i);
+                    if (av[i] >= T) append(F16 ? (float)av[i] : (float)av[i] * e.rsl, i);
             } else if (si >= 0) {
                 append(sv, si);
             }
@@ -474,7 +496,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             for (int qb = 0; qb < NQB; ++qb) { asm volatile("" ::"v"(acc[0][qb])); asm volatile("" ::"v"(acc[1][qb])); }
         } else if (false) {
 #else
-        if (MODE == MODE_FILTER) {
+        if constexpr (MODE == MODE_FILTER) {
 #endif
             const EpiCtx e = epi_begin(cu, ord, true);
             static_for<NQB>([&](auto QB_) __attribute__((always_inline)) { epi_pair(QB_, e); });
@@ -525,7 +547,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
 #pragma unroll
             for (int rs = 0; rs < 2; ++rs)
 #pragma unroll
-                for (int qb = 0; qb < NQB; ++qb) acc[rs][qb] = i32x4{0, 0, 0, 0};
+                for (int qb = 0; qb < NQB; ++qb) acc[rs][qb] = acc4_t{0, 0, 0, 0};
         }
     };
 
@@ -562,9 +584,15 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             lgkm_wait_asm<younger>(b[g % kBD]);
             const i32x4 a0 = __builtin_bit_cast(i32x4, ring[slot][0 * 2 + ks]);
             const i32x4 a1 = __builtin_bit_cast(i32x4, ring[slot][1 * 2 + ks]);
-            const i32x4 zero = {0, 0, 0, 0};
-            acc[0][qb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b[g % kBD], first && ks == 0 ? zero : acc[0][qb], 0, 0, 0);
-            acc[1][qb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b[g % kBD], first && ks == 0 ? zero : acc[1][qb], 0, 0, 0);
+            const acc4_t zero = {0, 0, 0, 0};
+            if constexpr (F16) {
+                typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+                acc[0][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a0), __builtin_bit_cast(h8, b[g % kBD]), first && ks == 0 ? zero : acc[0][qb], 0, 0, 0);
+                acc[1][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a1), __builtin_bit_cast(h8, b[g % kBD]), first && ks == 0 ? zero : acc[1][qb], 0, 0, 0);
+            } else {
+                acc[0][qb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b[g % kBD], first && ks == 0 ? zero : acc[0][qb], 0, 0, 0);
+                acc[1][qb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b[g % kBD], first && ks == 0 ? zero : acc[1][qb], 0, 0, 0);
+            }
             if constexpr (g + kBD < kGroups) {
                 constexpr int g2 = g + kBD;
                 lds_read_b128_asm<(((g2 % NQB) * 2) + (g2 / NQB)) * 1024>(b[g % kBD], qaddr);

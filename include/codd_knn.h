@@ -206,7 +206,8 @@ int codd_knn_ivf_search(codd_knn_index* index, const float* dev_queries, int B, 
  *            tile kernel's filter pass always fetches the block metadata by one LDS-DMA per tile); 0 = the device-wide bound everywhere), "fuse_fallback" (1: batches above 64 queries answer candidate-list
  *            overflows inside the finalize launch; 0: a launch of their own), "small_batch_max" (0; 1: a single query on
  *            <= 2M-row int8 shadows is answered by ONE launch — measured slower than the three-launch chain, see
- *            DESIGN.md §12, hence off), "ivf_share" (1: codd_knn_ivf_search scans a probed list once for all queries of the
+ *            DESIGN.md §12, hence off), "f16_tile" (1: the 2-byte filter of 129..256 queries on rows of 384 / 768 / 1152 ... elements runs
+ *            csrc/filter_i8.h's tile program on fp16 operands; 0: the first-generation kernel), "ivf_share" (1: codd_knn_ivf_search scans a probed list once for all queries of the
  *            batch that probe it, from 1,024 (query, list) pairs on; 0: once per pair),
  *            "debug_fail_shadow_alloc" (tests: the next N allocations of the 2-byte shadow fail);
  *            "profile" = N keeps N (start, stop) HIP-event pairs, one per heavy-kernel launch,
@@ -216,7 +217,7 @@ int codd_knn_ivf_search(codd_knn_index* index, const float* dev_queries, int B, 
  *            "device_bytes", "num_cus", "workspaces" (stream workspaces in use), "shadow8_builds", "shadow8_passes", "i8v2_passes",
  *            "shadow16_builds" (the bf16 shadow is built lazily, by the first search that needs it), "all_normalized",
  *            "shadow8_cooldowns", "shadow8_eps_r_micro", "shadow8_wide_blocks" (32-row blocks whose quantisation error is above
- *            0.04: tolerated up to 1 % of the blocks), "shadow16_alloc_failures", "small_batch_passes", and per kernel K in {scan, filter, sample, finalize}:
+ *            0.04: tolerated up to 1 % of the blocks), "shadow16_alloc_failures", "small_batch_passes", "f16_tile_passes", and per kernel K in {scan, filter, sample, finalize}:
  *            "events:K", "time_ns:K" (sum of the recorded launches; syncs on the last event)
  */
 int codd_knn_set_option(codd_knn_index* index, const char* key, int64_t value);

@@ -15,5 +15,8 @@
 #define ONEK_NQB 16
 #define ONEK_RES false
 #endif
-template __global__ void codd::i8_tile_kernel<ONEK_MODE, ONEK_S3, ONEK_NQB, ONEK_RES>(const uint4*, const uint4*, int64_t, int, int64_t, int64_t, const float*, codd::u64*,
+#ifndef ONEK_F16
+#define ONEK_F16 false
+#endif
+template __global__ void codd::i8_tile_kernel<ONEK_MODE, ONEK_S3, ONEK_NQB, ONEK_RES, ONEK_F16>(const uint4*, const uint4*, int64_t, int, int64_t, int64_t, const float*, codd::u64*,
                                                                                       codd::u64*, unsigned*, int, unsigned*, const float*, const float*, const float2*, float);
