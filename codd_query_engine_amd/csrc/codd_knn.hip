@@ -1690,7 +1690,8 @@ int ensure_filter_workspace(codd_knn_index* ix) {
         const void* tile_fns[] = {(const void*)&i8_tile_kernel<MODE_FILTER, 0>, (const void*)&i8_tile_kernel<MODE_FILTER, 1>, (const void*)&i8_tile_kernel<MODE_FILTER, 2>,
                                   (const void*)&i8_tile_kernel<MODE_FILTER, 0, 8>, (const void*)&i8_tile_kernel<MODE_FILTER, 1, 8>, (const void*)&i8_tile_kernel<MODE_FILTER, 2, 8>,
                                   (const void*)&i8_tile_kernel<MODE_FILTER, 3>, (const void*)&i8_tile_kernel<MODE_FILTER, 3, 8>,
-                                  (const void*)&i8_tile_kernel<MODE_FILTER, 2, 16, false, true>,
+                                  (const void*)&i8_tile_kernel<MODE_FILTER, 2, 16, false, true>, (const void*)&i8_tile_kernel<MODE_FILTER, 3, 16, false, true>,
+                                  (const void*)&i8_tile_kernel<MODE_FILTER, 4, 16, false, true>,
                                   (const void*)&i8_tile_kernel<MODE_FILTER, 1, 16, true>, (const void*)&i8_tile_kernel<MODE_FILTER, 0, 16, true>,
                                   (const void*)&i8_tile_kernel<MODE_FILTER, 1, 8, true>, (const void*)&i8_tile_kernel<MODE_FILTER, 0, 8, true>};
         for (const void* fn : tile_fns) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)i8_lds_bytes(MODE_FILTER)));
@@ -2012,8 +2013,14 @@ int filter_pass(codd_knn_index* ix, const float* qn, int nq, int k, uint32_t row
                        (int64_t)1, ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, nullptr, ix->rscale, ix->qmeta)
         if (tile_f16) {
             // (thr doubles as the 256 readable bytes the kernel's per-tile metadata request needs; fp16 operands carry no scales)
-            hipLaunchKernelGGL((i8_tile_kernel<MODE_FILTER, 2, 16, false, true>), g, b, i8_lds_bytes(MODE_FILTER), st, shadow, qfrag, n, nsteps, ntiles, (int64_t)1,
-                               ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, nullptr, nullptr, reinterpret_cast<const float2*>(ix->thr), 0.0f);
+            // rows of 768 elements are 12 K-steps of 64, rows of 384 are 6: the static forms of the tile program ("i8_pair" = 2); 18, 24, ...: run-time cursors
+#define CODD_LAUNCH_TILE16(S3)                                                                                                                            \
+    hipLaunchKernelGGL((i8_tile_kernel<MODE_FILTER, S3, 16, false, true>), g, b, i8_lds_bytes(MODE_FILTER), st, shadow, qfrag, n, nsteps, ntiles, (int64_t)1, \
+                       ix->thr, nullptr, ix->hits, ix->ctl->hit_cnt, ix->hit_cap_q, ix->ctl->flags, nullptr, nullptr, reinterpret_cast<const float2*>(ix->thr), 0.0f)
+            if (nsteps == 12 && ix->i8_pair == 2) CODD_LAUNCH_TILE16(4);
+            else if (nsteps == 6 && ix->i8_pair == 2) CODD_LAUNCH_TILE16(3);
+            else CODD_LAUNCH_TILE16(2);
+#undef CODD_LAUNCH_TILE16
         } else if (tile_v2) {
 #ifdef CODD_I8_EXP_STAMPS  // (diagnostic build: the filter pass writes its per-wave phase stamps over the sample's bucket keys, which anchor_thr has consumed)
 #define CODD_STAMP_BUF ix->bucket_max

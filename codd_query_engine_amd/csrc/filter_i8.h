@@ -193,8 +193,9 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
     constexpr bool kPair = TS >= 2;
     // TS = 3: the pair program for rows of EXACTLY 6 K-steps (768 elements, the headline shape), every cursor of the tile loop a
     // compile-time constant (run_static6 below)
-    constexpr bool kStatic6 = TS == 3;
-    static_assert(TS >= 0 && TS <= 3 && !(kPair && (RES || CODD_I8_LAG)), "pair barriers: staged tile-structured program only");
+    constexpr bool kStatic6 = TS >= 3;          // (the name is from the six-step form; TS = 4: the same program over 12 K-steps)
+    constexpr int NS = TS == 4 ? 12 : 6;        // K-steps per tile of the static program
+    static_assert(TS >= 0 && TS <= 4 && !(kPair && (RES || CODD_I8_LAG)), "pair barriers: staged tile-structured program only");
     static_assert(!kStatic6 || (MODE == MODE_FILTER && !CODD_I8_FUSE_EPI && !CODD_I8_SPREAD_VM), "the static six-step program: filter pass, standalone epilogue");
     static_assert(NQB == 16 || NQB == 8, "256 or 128 queries");
     static_assert(!F16 || (MODE == MODE_FILTER && !RES), "fp16 operands: the staged filter pass only");
@@ -652,9 +653,12 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             const unsigned ldsw = lds0 + (unsigned)(wave * 1024);   // this wave's share of a slice slot
             const int wq = wave * 1024;                              // ... and of a slice in the query buffer
             int u = first_u;                                          // run-tile ordinal of tile o
-            const char* A_cur = reinterpret_cast<const char*>(shadow8) + (int64_t)(u * tstride) * tile_bytes + wave * (6 * step_bytes);
+            const char* A_cur = reinterpret_cast<const char*>(shadow8) + (int64_t)(u * tstride) * tile_bytes + wave * (NS * step_bytes);
             const int64_t dA = (int64_t)(G * tstride) * tile_bytes;
-            unsigned px = 0u;                                         // 2 slots' bytes for odd tiles: slot ^ 2
+            // LDS slot of the tile's interval i: (NS o + i) & 3 = (i & 3) ^ 2 (o & 1) for 6 K-steps per tile, i & 3 for 12: px = the bytes to flip
+            unsigned px = 0u;
+            constexpr unsigned kPxStep = (unsigned)((NS & 3) * kSlotBytes);
+            unsigned tpar = 0u;                                       // tile parity: which of the two metadata buffers the tile uses
             // corpus loads "of interval I": step (I + 2) % 6 of this tile (I < 4) or the next one, into the ring slot interval I - 1 has
             // just consumed.  Intervals 1 and 3 issue their own in their heads and those of the EVEN interval behind them in their
             // tails, in front of their barriers (CODD_I8_EARLY_A): the heads of intervals 2 and 4 — which all eight waves run at the same
@@ -662,10 +666,10 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             // still staggered.  (Not interval 5 for the next tile's interval 0: the epilogue between them needs the third ring slot's
             // registers — with all three slots in flight it spilled 16 registers to scratch.)
             auto c_load = [&](auto I_, const char* A_next) __attribute__((always_inline)) {
-                constexpr int i = decltype(I_)::value % 6;
-                constexpr bool next_tile = decltype(I_)::value >= 4;
+                constexpr int i = decltype(I_)::value % NS;
+                constexpr bool next_tile = decltype(I_)::value >= NS - 2;
                 constexpr int li = ((i % 3) + 2) % 3;
-                constexpr int st = (i + 2) % 6;
+                constexpr int st = (i + 2) % NS;
                 const char* base = (next_tile ? A_next : A_cur) + st * step_bytes;
                 const i32x4 r = i8_rsrc(base, 4096);
                 i8_load_b128_nt<0>(ring[li][0], lane16, r);
@@ -676,35 +680,40 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             auto s_interval = [&](auto I_, const char* A_next) __attribute__((always_inline)) {
                 constexpr int i = decltype(I_)::value;
                 constexpr int ci = i % 3;
-                constexpr int st = (i + 2) % 6;                       // the step whose slice (and corpus fragments) are requested here
+                constexpr int st = (i + 2) % NS;                      // the step whose slice (and corpus fragments) are requested here
                 constexpr bool odd = (i & 1) != 0;
                 __builtin_amdgcn_sched_barrier(0);
                 const unsigned qaddr = lds0 + (((unsigned)((i & 3) * kSlotBytes)) ^ px) + (unsigned)lane16;
                 i32x4 b[kBD];
                 if (CODD_I8_EARLY_FRAGS) frag_prefetch(b, qaddr);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (i == 0) rs_dma(u, (int)(px != 0u));    // (tile parity picks the scale buffer: ord & 1)
+                if constexpr (i == 0) rs_dma(u, (int)tpar);          // (tile parity picks the scale buffer: ord & 1)
 #ifndef CODD_I8_EXP_NODMA
                 {
-                    const unsigned dst = ldsw + (((unsigned)(((i + 2) & 3) * kSlotBytes)) ^ px);
+                    // (the two bases pass through an opaque asm per interval: hipcc otherwise hoists every "base + constant" of the unrolled
+                    //  12-step tile out of the tile loop — 12 intervals x 8 of them — and spills 86 scalar registers to keep them)
+                    unsigned ldsw_i = ldsw;
+                    int wq_i = wq;
+                    if constexpr (NS > 6) asm volatile("" : "+s"(ldsw_i), "+s"(wq_i));   // (the six-step program keeps them: 106 SGPRs, none spilled)
+                    const unsigned dst = ldsw_i + (((unsigned)(((i + 2) & 3) * kSlotBytes)) ^ px);
 #pragma unroll
-                    for (int j = 0; j < kDmaPerSlice; ++j) i8_dma_b128_s(dst + j * 8192, lane16, rsrc_q, wq + st * kI8SliceBytes + j * 8192);
+                    for (int j = 0; j < kDmaPerSlice; ++j) i8_dma_b128_s(dst + j * 8192, lane16, rsrc_q, wq_i + st * kI8SliceBytes + j * 8192);
                 }
 #endif
-                constexpr bool e2 = (CODD_I8_EARLY_A & 1) != 0, e4 = (CODD_I8_EARLY_A & 2) != 0;
-                constexpr bool early_here = (i == 2 && e2) || (i == 4 && e4);   // this interval's loads went out in the tail of the one before
-                constexpr bool early_next = (i == 1 && e2) || (i == 3 && e4);   // ... and the next one's go out in this one's tail
+                // (even intervals from 2 on: bit 0 of CODD_I8_EARLY_A for 2, 6, 10, bit 1 for 4, 8)
+                auto early = [](int j) constexpr { return j >= 2 && j % 2 == 0 && (CODD_I8_EARLY_A & (j % 4 == 2 ? 1 : 2)) != 0; };
+                constexpr bool early_here = early(i);                    // this interval's loads went out in the tail of the one before
+                constexpr bool early_next = i + 1 < NS && early(i + 1);  // ... and the next one's go out in this one's tail
                 if constexpr (!early_here) c_load(I_, A_next);
                 // the corpus step requested two intervals ago; younger in the queue (issue order, kD = kDmaPerSlice, rs = the block
                 // metadata DMA of interval 0):
                 // (counted by walking the tile's issue order backwards from this interval's last operation to the loads of interval i - 2:
                 //  head(j) = [rs (j == 0)] [kD slice DMA] [4 corpus loads unless early], tail(j) = [4: the early loads of j + 1])
                 constexpr int kYounger = [&]() constexpr {
-                    auto early = [&](int j) constexpr { return (j == 2 && e2) || (j == 4 && e4); };
                     int n = 0;
                     // this interval's head, then backwards over tail(i-1), head(i-1), tail(i-2), head(i-2) until the loads of i - 2 are reached
                     n += (i == 0 ? 1 : 0) + kDmaPerSlice + (early(i) ? 0 : 4);
-                    const int j1 = (i + 5) % 6, j2 = (i + 4) % 6;
+                    const int j1 = (i + NS - 1) % NS, j2 = (i + NS - 2) % NS;
                     if (early(i)) n += 4;                                   // tail(i-1): this interval's own early loads
                     n += (j1 == 0 ? 1 : 0) + kDmaPerSlice + (early(j1) ? 0 : 4);   // head(i-1)
                     if (early(j1)) n += 4;                                  // tail(i-2): the early loads of i - 1
@@ -730,12 +739,7 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
             };
             for (int o = 0; o < my_tiles; ++o) {
                 const char* A_next = o + 1 < my_tiles ? A_cur + dA : A_cur;   // (past the last tile the loads stay on it: unconditional, never consumed)
-                s_interval(std::integral_constant<int, 0>{}, A_next);
-                s_interval(std::integral_constant<int, 1>{}, A_next);
-                s_interval(std::integral_constant<int, 2>{}, A_next);
-                s_interval(std::integral_constant<int, 3>{}, A_next);
-                s_interval(std::integral_constant<int, 4>{}, A_next);
-                s_interval(std::integral_constant<int, 5>{}, A_next);
+                static_for<NS>([&](auto I_) __attribute__((always_inline)) { s_interval(I_, A_next); });
                 // The workgroup's hit list is flushed HERE when it runs full: behind the tile's last barrier (three barriers after the
                 // previous tile's epilogue: every wave's appends are in, the count is stable) and in front of this tile's epilogue — the one
                 // point of the tile where only two of the three ring slots are in flight, so the flush code finds its registers (behind the
@@ -752,10 +756,11 @@ __global__ __launch_bounds__(512, 2) void i8_tile_kernel(const uint4* __restrict
                         __syncthreads();
                     }
                 }
-                epilogue(u, (int)(px != 0u));
+                epilogue(u, (int)tpar);
                 u += G;
                 A_cur = A_next;
-                px ^= (unsigned)(2 * kSlotBytes);
+                px ^= kPxStep;
+                tpar ^= 1u;
             }
             // (the corpus loads of the last two intervals are never consumed: nothing of this wave may be in flight past this point)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

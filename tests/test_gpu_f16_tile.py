@@ -41,7 +41,8 @@ def oracle_answer(raw, q, k, dtype):
         (70_001, 768, 129, 10, "f32"),    # the smallest batch that takes it
         (70_000, 768, 200, 100, "f32"),   # k = 100 (the filter needs 2k sample tiles)
         (50_000, 768, 256, 10, "bf16"),   # 2-byte stored rows (the shadow is fp16 whatever the storage type)
-        (30_000, 384, 256, 10, "f32"),    # 6 K-steps
+        (30_000, 384, 256, 10, "f32"),    # 6 K-steps: the static six-step form
+        (40_000, 1152, 256, 10, "bf16"),  # 18 K-steps: run-time cursors
         (6_000, 768, 256, 10, "f32"),     # 24 tiles: most workgroups have none
         (140_000, 768, 256, 10, "f32"),   # two and three tiles per workgroup
     ],
@@ -60,11 +61,17 @@ def test_fp16_tile_filter_is_exact(Index, n, d, B, k, dtype):
         assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref), rep
     assert ix.stat("f16_tile_passes") == 2 and ix.stat("shadow8_passes") == 0
     hits_tile = ix.stat("filter_hits")
+    ix.set_option("i8_pair", 1)           # the same rows through the tile program with run-time cursors
+    dist, rows = ix.search(q, k)
+    assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
+    assert ix.stat("f16_tile_passes") == 3 and ix.stat("filter_hits") - hits_tile == hits_tile // 2
+    ix.set_option("i8_pair", 2)
+    hits_tile = 2 * (ix.stat("filter_hits") // 3)
     ix.set_option("f16_tile", 0)          # the first-generation kernel on the same shadow: same answer, same candidate lists
     dist, rows = ix.search(q, k)
     assert np.array_equal(rows, i_ref) and np.array_equal(dist, d_ref)
-    assert ix.stat("f16_tile_passes") == 2
-    assert ix.stat("filter_hits") - hits_tile == hits_tile // 2, "both kernels test approx >= thr[q] on the same scores"
+    assert ix.stat("f16_tile_passes") == 3
+    assert ix.stat("filter_hits") - 3 * (hits_tile // 2) == hits_tile // 2, "both kernels test approx >= thr[q] on the same scores"
     ix.close()
 
 

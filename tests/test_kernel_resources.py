@@ -29,7 +29,7 @@ def test_hot_kernels_do_not_spill():
     # the second-generation int8 kernel (filter_i8.h): two waves per SIMD and no scratch (a reload inside the loop would wait
     # vmcnt(0) and drain the hand-counted prefetch)
     tile = [name for name in rows if "i8_tile_kernel" in name]
-    assert len(tile) == 17, report  # filter (generic / 3-step-multiple / 6-step-multiple / exactly-6-step rows) and sample, for 16 and for 8 query blocks, staged and resident slices; the fp16 filter
+    assert len(tile) == 19, report  # filter (generic / 3-step-multiple / 6-step-multiple / exactly-6-step rows) and sample, for 16 and for 8 query blocks, staged and resident slices; the fp16 filter
     for name in tile:
         # NO instantiation may touch scratch: the kernel issues its corpus loads and LDS-DMA by inline asm that hipcc cannot see
         # as in flight, so a ring[] / b[] register spilled between its load and the counted s_waitcnt would store stale bytes —
