@@ -57,6 +57,7 @@ while time.time() < t_end:
         df, rf = ix.search_tensors(q, k)
     used_filter = ix.stat("filter_passes") > 0
     tile_passes = globals().get("tile_passes", 0) + ix.stat("i8v2_passes")
+    f16_passes = globals().get("f16_passes", 0) + ix.stat("f16_tile_passes")
     fallbacks += ix.stat("fallback_queries")
     passes8 += ix.stat("shadow8_passes")
     ix.set_option("filter", 0)
@@ -68,5 +69,5 @@ while time.time() < t_end:
         bad = (rf != re_).any(dim=1).nonzero().flatten().tolist()[:5]
         print(f"MISMATCH n={n} d={d} dtype={dtype} B={B} k={k} kind={kind} filter={used_filter} queries={bad}", flush=True)
     ix.close()
-print(f"soak: {cases} cases, {fails} mismatches, {fallbacks} fallback queries, {passes8} int8 passes ({globals().get('tile_passes', 0)} through the tile kernel) in {budget:.0f} s")
+print(f"soak: {cases} cases, {fails} mismatches, {fallbacks} fallback queries, {passes8} int8 passes ({globals().get('tile_passes', 0)} through the tile kernel), {globals().get('f16_passes', 0)} fp16 tile passes in {budget:.0f} s")
 sys.exit(1 if fails else 0)
