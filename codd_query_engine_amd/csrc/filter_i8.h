@@ -50,8 +50,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kI8SliceBytes = 32768;  // one 128-wide K slice of the 256-query block
 constexpr int kI8RsBufs = 2;          // row-scale buffers (tile ordinal & 1): a tile's scales are read (its epilogue, at the start of the next tile) before the tile after next requests its own
 constexpr int kI8RsStride = 272;      // floats per buffer: 256 row scales + 8 per-wave maxima (+ pad)
-#if !CODD_EXPERIMENTS && (defined(CODD_I8_BDEPTH) || defined(CODD_I8_EARLY_FRAGS) || defined(CODD_I8_LAG) || defined(CODD_I8_SPREAD_VM) || defined(CODD_I8_FUSE_EPI))
-#error "CODD_I8_BDEPTH / CODD_I8_EARLY_FRAGS / CODD_I8_LAG are schedule experiments: only their defaults are under test; -DCODD_EXPERIMENTS=1 builds (build_variant) may set them"
+#if !CODD_EXPERIMENTS && (defined(CODD_I8_BDEPTH) || defined(CODD_I8_EARLY_FRAGS) || defined(CODD_I8_LAG) || defined(CODD_I8_SPREAD_VM) || defined(CODD_I8_FUSE_EPI) || \
+                          defined(CODD_I8_EARLY_A))
+#error "CODD_I8_BDEPTH / CODD_I8_EARLY_FRAGS / CODD_I8_LAG / CODD_I8_EARLY_A ... are schedule experiments: only their defaults are under test; -DCODD_EXPERIMENTS=1 builds (build_variant) may set them"
 #endif
 #ifndef CODD_I8_BDEPTH
 #define CODD_I8_BDEPTH 4              // query-fragment register sets in flight
