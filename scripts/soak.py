@@ -55,6 +55,18 @@ while time.time() < t_end:
     if rng.random() < 0.5:  # the same index searched again right away (stale LDS / DMA / counter state must not leak)
         q = torch.randn((B, d), generator=g, device="cuda")
         df, rf = ix.search_tensors(q, k)
+    # the same search twice more: the candidate lists (their SIZE: order is up to the atomics) must not change between identical searches — a race in
+    # the filter kernels' schedule shows there long before it costs a true neighbour
+    hh = []
+    for _ in range(2):
+        h0 = ix.stat("filter_hits")
+        ix.search_tensors(q, k)
+        hh.append(ix.stat("filter_hits") - h0)
+    # (only where nothing legitimately changes between two searches: candidate lists that overflow are cut off at a point the atomics' order decides, and an index
+    #  that cools down from the int8 filter to the 2-byte one after measuring its survivors takes another path the second time)
+    if hh[0] != hh[1] and (kind == "random" or tile_only):
+        fails += 1
+        print(f"NON-DETERMINISTIC candidate lists n={n} d={d} dtype={dtype} B={B} k={k} kind={kind}: {hh}", flush=True)
     used_filter = ix.stat("filter_passes") > 0
     tile_passes = globals().get("tile_passes", 0) + ix.stat("i8v2_passes")
     f16_passes = globals().get("f16_passes", 0) + ix.stat("f16_tile_passes")

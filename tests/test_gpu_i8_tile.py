@@ -237,3 +237,33 @@ def test_forty_thousand_near_copies_stay_on_the_filter_path(Index):
     assert ix.stat("fallback_queries") == 0
     assert ix.stat("filter_survivors") >= 200 * 40_000
     ix.close()
+
+
+@pytest.mark.parametrize("shadow8", [1, 0])
+def test_candidate_lists_are_deterministic(Index, shadow8):
+    """A race in the hand-ordered schedule (a stale slice, a load consumed before its counted wait) first shows as candidates that come
+    and go between identical searches — long before it costs a true neighbour (round 3: the hazard of DESIGN.md 12.5, and a schedule
+    variant that lost a few hundred of 12.8 million candidates per run while its top-10 still validated).  Ten identical searches
+    through the int8 tile program (shadow8 = 1) and through its fp16 form (shadow8 = 0) must produce the same number of candidates
+    and survivors every time."""
+    rng = np.random.default_rng(99)
+    n, d, B, k = 300_000, 768, 256, 10
+    raw = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal((B, d)).astype(np.float32)
+    ix = build(Index, raw)
+    ix.set_option("shadow8", shadow8)
+    ix.set_option("shadow8_cooldown", 0)
+    counts = []
+    ref = None
+    for rep in range(10):
+        h0, s0 = ix.stat("filter_hits"), ix.stat("filter_survivors")
+        dist, rows = ix.search(q, k)
+        counts.append((ix.stat("filter_hits") - h0, ix.stat("filter_survivors") - s0))
+        if ref is None:
+            ref = (dist.copy(), rows.copy())
+        assert np.array_equal(rows, ref[1]) and np.array_equal(dist, ref[0]), rep
+    assert len(set(counts)) == 1, counts
+    assert ix.stat("i8v2_passes" if shadow8 else "f16_tile_passes") == 10
+    d_ref, i_ref = oracle_answer(raw, q, k, "f32")
+    assert np.array_equal(ref[1], i_ref) and np.array_equal(ref[0], d_ref)
+    ix.close()
