@@ -160,7 +160,8 @@ def test_overflow_falls_back_and_stays_exact(Index):
     ix.close()
 
 
-@pytest.mark.parametrize("B,d,dtype,fuse", [(200, 768, "f32", 1), (200, 768, "f32", 0), (96, 256, "bf16", 1), (130, 1024, "f16", 1)])
+@pytest.mark.parametrize("B,d,dtype,fuse", [(200, 768, "f32", 1), (200, 768, "f32", 0), (96, 256, "bf16", 1), (130, 1024, "f16", 1),
+                                            (200, 768, "bf16", 1)])   # (the last one: the 2-byte filter through the tile program on fp16 operands)
 def test_overflow_in_a_large_batch_is_answered_inside_the_finalize_launch(Index, B, d, dtype, fuse):
     """Round 3: for batches above 64 queries finalize and the exact-scan fallback are ONE launch (finalize_fb_kernel: its scan
     workgroups derive the queue from the hit counters).  Same overflow as above — 5,000 near-copies, candidate lists shrunk to
